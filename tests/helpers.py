@@ -1,0 +1,60 @@
+"""Shared helpers for the parity tests (seeded inputs identical to tools/make_golden_forward.py)."""
+import os
+
+import numpy as np
+import torch
+
+from cellvit_amd.spec import cellvit256_config, cellvit_sam_config
+from cellvit_amd.weights import make_state_dict, normalize_tile, synthetic_tile_u8
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = {
+    # name: (config factory, batch, H, W)
+    "vit256_256": (lambda: cellvit256_config(), 1, 256, 256),
+    "vit256_b2_128x192": (lambda: cellvit256_config(), 2, 128, 192),
+    "samb_128": (lambda: cellvit_sam_config("SAM-B"), 2, 128, 128),
+    "samh_256": (lambda: cellvit_sam_config("SAM-H"), 1, 256, 256),
+    "samh_1024": (lambda: cellvit_sam_config("SAM-H"), 1, 1024, 1024),
+}
+
+
+def make_input(batch, h, w, first_tile=0):
+    xs = []
+    for b in range(batch):
+        t = synthetic_tile_u8(first_tile + b, size=max(h, w), he_like=(b % 2 == 1))[:h, :w]
+        xs.append(normalize_tile(t))
+    return torch.from_numpy(np.stack(xs))
+
+
+def load_case(name):
+    mk, b, h, w = CASES[name]
+    cfg = mk()
+    sd = make_state_dict(cfg, seed=0)
+    x = make_input(b, h, w)
+    gold = dict(np.load(os.path.join(GOLDEN, f"forward_{name}.npz")))
+    return cfg, sd, x, gold
+
+
+def compare_outputs(out, gold, atol, rtol=0.0, keys=("tissue_types", "nuclei_binary_map", "hv_map",
+                                                      "nuclei_type_map", "tokens")):
+    """Return dict key -> max abs error; assert within tolerance."""
+    errs = {}
+    for k in keys:
+        a = out[k].detach().float().cpu().numpy()
+        if k in gold:
+            g = gold[k]
+            assert a.shape == g.shape, (k, a.shape, g.shape)
+            e = float(np.abs(a - g).max())
+            errs[k] = e
+            assert np.allclose(a, g, atol=atol, rtol=rtol), f"{k}: max abs err {e} > {atol}"
+        elif k + "_center" in gold:
+            gc = gold[k + "_center"]
+            c = gc.shape[-1]
+            H, W = a.shape[-2:]
+            y0, x0 = (H - c) // 2, (W - c) // 2
+            e1 = float(np.abs(a[..., y0:y0 + c, x0:x0 + c] - gc).max())
+            e2 = float(np.abs(a[..., :c, :c] - gold[k + "_corner"]).max())
+            errs[k] = max(e1, e2)
+            assert errs[k] <= atol, f"{k}: crop max abs err {errs[k]} > {atol}"
+    return errs

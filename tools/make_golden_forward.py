@@ -1,0 +1,78 @@
+"""Generate tests/golden/forward_*.npz by running the IMPORTED REFERENCE (development container
+only; /root/reference never travels to the GPU box) on the seeded weights of
+cellvit_amd.weights and seeded synthetic tiles.  Commit the outputs together with this script.
+
+    python tools/make_golden_forward.py            # all cases
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import ref_import  # noqa: E402
+from cellvit_amd.spec import cellvit256_config, cellvit_sam_config  # noqa: E402
+from cellvit_amd.weights import make_state_dict, normalize_tile, synthetic_tile_u8  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def make_input(batch, h, w, first_tile=0):
+    xs = []
+    for b in range(batch):
+        t = synthetic_tile_u8(first_tile + b, size=max(h, w), he_like=(b % 2 == 1))[:h, :w]
+        xs.append(normalize_tile(t))
+    return torch.from_numpy(np.stack(xs))
+
+
+def run(name, model, cfg, batch, h, w, full=True, crop=64):
+    sd = make_state_dict(cfg, seed=0)
+    print(name, model.load_state_dict(sd))
+    model.eval()
+    x = make_input(batch, h, w)
+    t = time.time()
+    with torch.no_grad():
+        out = model(x, retrieve_tokens=True)
+    print(f"  reference forward {time.time() - t:.1f}s")
+    rec = {"meta_shape": np.array([batch, h, w]), "tissue_types": out["tissue_types"].numpy()}
+    for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map", "tokens"):
+        v = out[k].numpy()
+        if full:
+            rec[k] = v
+        else:  # large tile: keep a centre crop + corner crop + global statistics
+            H, W = v.shape[-2:]
+            c = min(crop, H)
+            y0, x0 = (H - c) // 2, (W - c) // 2
+            rec[k + "_center"] = v[..., y0:y0 + c, x0:x0 + c].copy()
+            rec[k + "_corner"] = v[..., :c, :c].copy()
+            rec[k + "_stats"] = np.array([v.mean(), v.std(), v.min(), v.max(),
+                                          np.abs(v).mean()], dtype=np.float64)
+            if k != "tokens":
+                rec[k + "_argmax_hist"] = np.bincount(v.argmax(1).ravel(), minlength=v.shape[1])
+    np.savez_compressed(os.path.join(OUT, f"forward_{name}.npz"), **rec)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    cv = ref_import.import_cellvit()
+    which = sys.argv[1:] or ["vit256_256", "vit256_b2_128x192", "samb_128", "samh_256", "samh_1024"]
+    if "vit256_256" in which:   # BASELINE.json configs[0]
+        run("vit256_256", cv.CellViT256(None, 6, 19), cellvit256_config(), 1, 256, 256)
+    if "vit256_b2_128x192" in which:   # batch > 1, non-square (bicubic pos-embed w/h handling)
+        run("vit256_b2_128x192", cv.CellViT256(None, 6, 19), cellvit256_config(), 2, 128, 192)
+    if "samb_128" in which:     # small SAM: window padding (8 -> 14) + interpolated global rel-pos
+        run("samb_128", cv.CellViTSAM(None, 6, 19, "SAM-B"), cellvit_sam_config("SAM-B"), 2, 128, 128)
+    if "samh_256" in which:
+        run("samh_256", cv.CellViTSAM(None, 6, 19, "SAM-H"), cellvit_sam_config("SAM-H"), 1, 256, 256)
+    if "samh_1024" in which:    # BASELINE.json configs[2] shape; crops + statistics only
+        run("samh_1024", cv.CellViTSAM(None, 6, 19, "SAM-H"), cellvit_sam_config("SAM-H"), 1, 1024, 1024,
+            full=False)
+
+
+if __name__ == "__main__":
+    main()
