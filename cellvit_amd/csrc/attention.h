@@ -1,0 +1,44 @@
+// Flash-style multi-head attention for both CellViT encoders, plus the decomposed relative
+// position terms of the SAM encoder.
+//   ViT-S  : softmax((q·kᵀ)·hd^-½)·v                         vits_histo.py:174-185
+//   SAM    : softmax((q·hd^-½)·kᵀ + rel_h + rel_w)·v          SAM/image_encoder.py:235-257, 354-392
+// Layouts (written by the QKV GEMM epilogue, gemm.h OUT_QKV):
+//   Q, K : [S*heads, L, hd]   V^T : [S*heads, hd, Lp]          S = images (global) or windows
+#pragma once
+#include "common.h"
+
+namespace cva {
+
+struct AttnParams {
+    const void* Q; const void* K; const void* Vt;   // T
+    const float* relh;      // [S*heads, L, KH] fp32 or null
+    const float* relw;      // [S*heads, L, KW]
+    void* out;              // T [tokens, D]
+    int S, heads, L, Lp, hd, D;
+    int nk;                 // number of keys (== L)
+    int KH, KW;             // key grid (rel-pos only); key = kh*KW + kw
+    float scale;
+    // output row mapping (inverse of the QKV scatter)
+    int ntok;               // tokens per image
+    int win, gw, gh, nwx, nwy;
+};
+
+struct RelPosParams {
+    const void* Q;          // T [S*heads, L, hd]
+    const float* tab_h;     // [2*KH-1, hd] fp32 (already resized to the key grid)
+    const float* tab_w;     // [2*KW-1, hd]
+    float* relh; float* relw;
+    int SH, L, hd, KH, KW;  // query grid == key grid (self attention): q = qy*KW + qx
+};
+
+struct PadKVParams {        // window mode: keys/values of zero-padded tokens are the qkv biases
+    void* K; void* Vt;      // T
+    const float* qkv_bias;  // [3*D]
+    int B, heads, hd, D, L, Lp, win, gw, gh, nwx, nwy;
+};
+
+template <typename T> int launch_attention(const AttnParams& p, hipStream_t stream);
+template <typename T> int launch_relpos(const RelPosParams& p, hipStream_t stream);
+template <typename T> int launch_pad_kv(const PadKVParams& p, hipStream_t stream);
+
+}  // namespace cva

@@ -1,0 +1,43 @@
+// Bandwidth-bound helper kernels of the forward pass (layout changes, LayerNorm, heads).
+#pragma once
+#include "common.h"
+
+namespace cva {
+
+// LayerNorm over the last dim (eps inside sqrt, biased variance): nn.LayerNorm(eps=1e-6) of both
+// encoders (cellvit.py:99, 559) and LayerNorm2d of the SAM neck on NHWC data (SAM/utils.py:38-50).
+// in: fp32 rows [M, C] at stride ld_in; out: T or fp32 [M, C] contiguous.
+template <typename T>
+int launch_layernorm(const float* in, long ld_in, const float* gamma, const float* beta, void* out,
+                     int out_f32, int M, int C, float eps, hipStream_t stream);
+
+// x fp32 NCHW [B,3,H,W] -> patch matrix [B*(H/16)*(W/16), 768] of T, k = c*256 + ky*16 + kx
+// (the flattening of Conv2d(3, D, 16, 16).weight — vits_histo.py:273-280, image_encoder.py:418-426).
+template <typename T> int launch_patchify(const float* x, void* out, int B, int H, int W, hipStream_t stream);
+
+// x fp32 NCHW [B,3,H,W] -> NHWC [B,H,W,8] of T, channels 3..7 zero (decoder0 input, cellvit.py:182,241).
+template <typename T> int launch_nchw3_to_nhwc8(const float* x, void* out, int B, int H, int W, hipStream_t stream);
+
+// fp32 token rows -> T rows, optionally dropping a leading cls row per image (cellvit.py:186-189).
+// in: [B, rpi_in, C] (rpi_in = ntok incl. cls); out: [B, ntok_out, C] with ntok_out = rpi_in - skip.
+template <typename T>
+int launch_cast_tokens(const float* in, void* out, int B, int rpi_in, int skip, int C, hipStream_t stream);
+
+// fp32 -> T elementwise copy
+template <typename T> int launch_cast(const float* in, void* out, long n, hipStream_t stream);
+
+// ViT cls row: out[b*ntok + 0, :] = cls + pos[0]   (vits_histo.py:408-413)
+int launch_cls_rows(const float* cls, const float* pos0, float* tokens, int B, int ntok, int C, hipStream_t stream);
+
+// mean over rows per image: in fp32 [B, R, C] -> out fp32 [B, C]   (utils.py:231-233)
+int launch_mean_rows(const float* in, float* out, int B, int R, int C, hipStream_t stream);
+
+// 1x1 output conv of a decoder branch (cellvit.py:309-315) fused with the NHWC->NCHW permute:
+// feat T [B*H*W, 64] · Wt[n_out, 64] + b -> logits fp32 [B, n_out, H*W].
+// argmax_out (u8 [B*H*W]) optional: argmax over the first n_arg channels (== argmax of softmax,
+// cellvit.py:369-374 — softmax is monotone, ties resolve to the lowest index as torch.argmax).
+template <typename T>
+int launch_head1x1(const void* feat, const float* Wt, const float* bias, float* logits, uint8_t* argmax_out,
+                   int n_arg, long npix_per_img, int B, int n_out, hipStream_t stream);
+
+}  // namespace cva

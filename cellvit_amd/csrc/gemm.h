@@ -1,0 +1,47 @@
+// Tiled MFMA contraction  C[M,N] = A[M,K] · W[N,K]^T  with fused prologue gathers and epilogues.
+// One kernel serves every dense contraction on the CellViT hot path:
+//   * nn.Linear layers of both encoders (QKV / proj / fc1 / fc2 / heads)      — A linear
+//   * patch-embed conv k16 s16 (after patchify)                               — A linear
+//   * Conv2d 3x3 p1 of the U-Net decoder as an im2col-FREE implicit GEMM      — A gathered from
+//     one or two NHWC sources (the skip ‖ upsampled concat is never materialised)
+//   * ConvTranspose2d k2 s2 as one GEMM with a pixel-shuffle scatter epilogue
+#pragma once
+#include "common.h"
+
+namespace cva {
+
+enum : int { A_LINEAR = 0, A_CONV3 = 1 };
+enum : int { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+enum : int { OUT_LINEAR = 0, OUT_QKV = 1, OUT_CONVT = 2 };
+
+struct GemmParams {
+    // ---- problem ----
+    int M, N, K;            // K = logical contraction length (multiple of the 16-B piece)
+    const void* A;          // A_LINEAR: [rows, lda] of T.  A_CONV3: source 1 (NHWC, C1 channels)
+    const void* A2;         // A_CONV3: source 2 (NHWC, C2 channels) or null
+    const void* W;          // [N, ldw] of T, K-contiguous (nn.Linear layout), zero padded to ldw
+    int lda, ldw;
+    // A_LINEAR row remap: arow = m + (m / a_rpi) * a_extra + a_off   (a_rpi == 0: identity)
+    int a_rpi, a_extra, a_off;
+    // A_CONV3 geometry: M = B*H*W output pixels, K = 9*(C1+C2)
+    int H, Wd, C1, C2;
+    // ---- epilogue ----
+    const float* bias;      // [N] or null
+    int act;
+    const float* res;       // fp32 residual [*, ldres] or null; row = res_mod ? m % res_mod : orow
+    int ldres, res_mod;
+    int out_mode;
+    int out_f32;            // 1: store fp32, 0: store T
+    void* out;              // OUT_LINEAR: [rows, ldc];  OUT_CONVT: NHWC [B, 2H, 2W, N/4]
+    int ldc;
+    // OUT_LINEAR row remap: orow = m + (m / o_rpi) * o_extra + o_off (o_rpi == 0: identity)
+    int o_rpi, o_extra, o_off;
+    // OUT_QKV: scatter q,k -> [S*heads, L, hd], v -> V^T [S*heads, hd, Lp]
+    void* q_out; void* k_out; void* vt_out;
+    int D, hd, heads, ntok, L, Lp;   // ntok tokens per image (incl. cls for ViT)
+    int win, gw, gh, nwx, nwy;       // win > 0: window partition of the gh x gw token grid
+};
+
+template <typename T> int launch_gemm(const GemmParams& p, int a_mode, hipStream_t stream);
+
+}  // namespace cva

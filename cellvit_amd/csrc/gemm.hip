@@ -1,0 +1,224 @@
+// MFMA tile contraction for gfx950 — see gemm.h for the role of each mode.
+//
+// Geometry: 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 4 x 4
+// fragments of v_mfma_f32_16x16x32_f16 (or 8 x v_mfma_f32_16x16x4_f32 in the fp32 parity path).
+// K is consumed in 128-byte rows (64 halves / 32 floats) staged through LDS with a +32 B row
+// pitch (bank-conflict-free ds_read_b128 fragment reads); the next K tile is prefetched into
+// registers while the current one is multiplied.
+#include "gemm.h"
+
+namespace cva {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NT = 256;
+
+template <typename T, int AMODE, int OMODE>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
+    using TR = Traits<T>;
+    constexpr int BK = TR::BK, PE = TR::PIECE, PITCH = lds_pitch<T>(BK);
+    constexpr int PPR = BK / PE;            // 16-B pieces per tile row (8)
+    constexpr int RPP = NT / PPR;           // rows covered per load pass (32)
+    constexpr int APASS = BM / RPP, BPASS = BN / RPP;
+    constexpr int KSTEPS = BK / 32;
+
+    __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * PITCH];
+    T* As = smem;
+    T* Bs = smem + BM * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+
+    const int pc = tid % PPR, pr = tid / PPR;
+    const T* __restrict__ Ap = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ A2p = reinterpret_cast<const T*>(p.A2);
+    const T* __restrict__ Wp = reinterpret_cast<const T*>(p.W);
+
+    // ---- per-thread row descriptors of the A and W tiles (fixed over the K loop) ----
+    long a_off[APASS];      // A_LINEAR: element offset of the row; A_CONV3: unused
+    int a_b[APASS], a_y[APASS], a_x[APASS];
+    bool a_ok[APASS];
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int m = m0 + pr + RPP * i;
+        a_ok[i] = m < p.M;
+        if (AMODE == A_LINEAR) {
+            long row = m;
+            if (p.a_rpi > 0) row = (long)m + (long)(m / p.a_rpi) * p.a_extra + p.a_off;
+            a_off[i] = row * (long)p.lda;
+            a_b[i] = a_y[i] = a_x[i] = 0;
+        } else {
+            const int hw = p.H * p.Wd;
+            const int b = m / hw, r = m - b * hw;
+            a_b[i] = b; a_y[i] = r / p.Wd; a_x[i] = r - a_y[i] * p.Wd;
+            a_off[i] = 0;
+        }
+    }
+    long w_off[BPASS];
+    bool w_ok[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        const int n = n0 + pr + RPP * i;
+        w_ok[i] = n < p.N;
+        w_off[i] = (long)n * p.ldw;
+    }
+    const int ctot = p.C1 + p.C2;
+    const int ppt = (AMODE == A_CONV3) ? ctot / PE : 1;   // pieces per filter tap
+
+    Piece ra[APASS], rb[BPASS];
+    auto fetch = [&](int k0) {
+        const int k = k0 + pc * PE;
+        if (AMODE == A_LINEAR) {
+            const bool kok = k < p.K;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i)
+                ra[i] = (a_ok[i] && kok) ? load_piece(Ap + a_off[i] + k) : zero_piece();
+        } else {
+            const int q = k / PE;
+            const int tap = q / ppt;
+            const int c = (q - tap * ppt) * PE;
+            const bool kok = tap < 9;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const bool second = c >= p.C1;
+            const T* __restrict__ src = second ? A2p : Ap;
+            const int cs = second ? p.C2 : p.C1;
+            const int cc = second ? c - p.C1 : c;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+                const bool ok = kok && a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+                ra[i] = ok ? load_piece(src + ((long)(a_b[i] * p.H + yy) * p.Wd + xx) * cs + cc) : zero_piece();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) rb[i] = w_ok[i] ? load_piece(Wp + w_off[i] + k) : zero_piece();
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+
+    const int nk = (p.K + BK - 1) / BK;
+    fetch(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) store_piece(As + (pr + RPP * i) * PITCH + pc * PE, ra[i]);
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) store_piece(Bs + (pr + RPP * i) * PITCH + pc * PE, rb[i]);
+        __syncthreads();
+        if (kt + 1 < nk) fetch((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            typename TR::Frag a[4], b[4];
+            const int ko = ks * 32 + (lane >> 4) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = TR::load_frag(As + (wm * 64 + i * 16 + (lane & 15)) * PITCH + ko);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = TR::load_frag(Bs + (wn * 64 + j * 16 + (lane & 15)) * PITCH + ko);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) TR::mma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // C fragment layout: lane l, reg r -> row (l>>4)*4 + r, col l&15.
+    const int colb = n0 + wn * 64 + (lane & 15);
+    const int rowb = m0 + wm * 64 + (lane >> 4) * 4;
+    T* outT = reinterpret_cast<T*>(p.out);
+    float* outF = reinterpret_cast<float*>(p.out);
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = colb + j * 16;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+        // column-dependent scatter terms
+        long col_term = 0; int which = 0;
+        if (OMODE == OUT_QKV) {
+            which = n / p.D;
+            const int c = n - which * p.D;
+            const int h = c / p.hd, d = c - h * p.hd;
+            // q,k: ((s*heads+h)*L + pos)*hd + d ; vt: ((s*heads+h)*hd + d)*Lp + pos
+            col_term = (which < 2) ? ((long)h * p.L * p.hd + d) : (((long)h * p.hd + d) * p.Lp);
+        } else if (OMODE == OUT_CONVT) {
+            const int cout = p.N >> 2;
+            const int dd = n / cout, co = n - dd * cout;
+            const int dy = dd >> 1, dx = dd & 1;
+            col_term = ((long)dy * (2 * p.Wd) + dx) * cout + co;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = rowb + i * 16 + r;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (p.act == ACT_GELU) v = gelu_erf(v);
+                else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                if (OMODE == OUT_LINEAR) {
+                    long orow = m;
+                    if (p.o_rpi > 0) orow = (long)m + (long)(m / p.o_rpi) * p.o_extra + p.o_off;
+                    if (p.res) {
+                        const long rrow = p.res_mod > 0 ? (long)(m % p.res_mod) : orow;
+                        v += p.res[rrow * p.ldres + n];
+                    }
+                    const long o = orow * (long)p.ldc + n;
+                    if (p.out_f32) outF[o] = v; else outT[o] = TR::from_float(v);
+                } else if (OMODE == OUT_CONVT) {
+                    const int hw = p.H * p.Wd;
+                    const int b = m / hw, rr = m - b * hw;
+                    const int y = rr / p.Wd, x = rr - y * p.Wd;
+                    const int cout = p.N >> 2;
+                    const long o = (((long)b * 2 * p.H + 2 * y) * (2 * p.Wd) + 2 * x) * cout + col_term;
+                    if (p.out_f32) outF[o] = v; else outT[o] = TR::from_float(v);
+                } else {  // OUT_QKV
+                    const int b = m / p.ntok, t = m - b * p.ntok;
+                    int s = b, pos = t;
+                    if (p.win > 0) {
+                        const int gy = t / p.gw, gx = t - gy * p.gw;
+                        const int wy = gy / p.win, wx = gx / p.win;
+                        s = (b * p.nwy + wy) * p.nwx + wx;
+                        pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
+                    }
+                    const T tv = TR::from_float(v);
+                    if (which == 0) reinterpret_cast<T*>(p.q_out)[((long)s * p.heads * p.L + pos) * p.hd + col_term] = tv;
+                    else if (which == 1) reinterpret_cast<T*>(p.k_out)[((long)s * p.heads * p.L + pos) * p.hd + col_term] = tv;
+                    else reinterpret_cast<T*>(p.vt_out)[(long)s * p.heads * p.hd * p.Lp + col_term + pos] = tv;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+template <typename T>
+int launch_gemm(const GemmParams& p, int a_mode, hipStream_t stream) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (tiles <= 0) return 0;
+    const dim3 g(tiles), b(NT);
+    if (a_mode == A_CONV3) {
+        if (p.out_mode != OUT_LINEAR) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL((gemm_kernel<T, A_CONV3, OUT_LINEAR>), g, b, 0, stream, p);
+    } else if (p.out_mode == OUT_LINEAR) {
+        hipLaunchKernelGGL((gemm_kernel<T, A_LINEAR, OUT_LINEAR>), g, b, 0, stream, p);
+    } else if (p.out_mode == OUT_QKV) {
+        hipLaunchKernelGGL((gemm_kernel<T, A_LINEAR, OUT_QKV>), g, b, 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<T, A_LINEAR, OUT_CONVT>), g, b, 0, stream, p);
+    }
+    return (int)hipGetLastError();
+}
+
+template int launch_gemm<half_t>(const GemmParams&, int, hipStream_t);
+template int launch_gemm<float>(const GemmParams&, int, hipStream_t);
+
+}  // namespace cva
