@@ -1,0 +1,94 @@
+"""ctypes binding of libcellvit_amd.so (the C ABI declared in include/cellvit_amd.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails the product
+path raises.  The library is built in-tree by ``python -m cellvit_amd.build`` (also called from
+``__graft_entry__.build()``) so that it travels to the GPU box with the repository snapshot.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcellvit_amd.so")
+
+CV_OK, CV_ERR_INVALID, CV_ERR_HIP, CV_ERR_STATE, CV_ERR_SHAPE, CV_ERR_UNSUPPORTED, CV_ERR_MISSING = range(7)
+DTYPE_F16, DTYPE_F32 = 0, 1
+
+
+class cv_config(C.Structure):
+    _fields_ = [
+        ("arch", C.c_int32), ("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32),
+        ("mlp_ratio", C.c_int32), ("extract_layers", C.c_int32 * 4),
+        ("num_nuclei_classes", C.c_int32), ("num_tissue_classes", C.c_int32), ("regression_loss", C.c_int32),
+        ("patch_size", C.c_int32), ("window_size", C.c_int32), ("n_global", C.c_int32),
+        ("global_attn_indexes", C.c_int32 * 8), ("neck_chans", C.c_int32), ("compute_dtype", C.c_int32),
+    ]
+
+
+class cv_outputs(C.Structure):
+    _fields_ = [
+        ("tissue_types", C.c_void_p), ("nuclei_binary_map", C.c_void_p), ("hv_map", C.c_void_p),
+        ("nuclei_type_map", C.c_void_p), ("regression_map", C.c_void_p), ("tokens_nhwc", C.c_void_p),
+        ("binary_argmax", C.c_void_p), ("type_argmax", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); the CPU test suite checks that every one of these resolves.
+SYMBOLS = {
+    "cv_last_error": (C.c_char_p, []),
+    "cv_create": (C.c_int, [C.POINTER(cv_config), C.POINTER(C.c_void_p)]),
+    "cv_destroy": (C.c_int, [C.c_void_p]),
+    "cv_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "cv_finalize": (C.c_int, [C.c_void_p]),
+    "cv_set_geometry": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "cv_set_derived": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "cv_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(cv_outputs), C.c_void_p]),
+    "cv_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
+    "cv_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "cv_op_linear": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cv_op_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int, C.c_float, C.c_void_p]),
+    "cv_op_conv3x3": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cv_op_convT2x2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cv_op_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP extension; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension with `python -m cellvit_amd.build` "
+            "(cellvit_amd has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the ABI and the binding drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+_EXC = {
+    CV_ERR_INVALID: ValueError, CV_ERR_HIP: RuntimeError, CV_ERR_STATE: RuntimeError,
+    CV_ERR_SHAPE: AssertionError, CV_ERR_UNSUPPORTED: NotImplementedError, CV_ERR_MISSING: RuntimeError,
+}
+
+
+def check(rc: int) -> None:
+    """Map a C status to the exception type the reference raises at the same place."""
+    if rc == CV_OK:
+        return
+    msg = load().cv_last_error()
+    msg = msg.decode("utf-8", "replace") if msg else f"cellvit_amd error {rc}"
+    raise _EXC.get(rc, RuntimeError)(msg)

@@ -1,0 +1,850 @@
+// C-ABI model assembly: weight packing (cv_finalize) and the launch sequence of one forward pass
+// (cv_forward).  Host code only — the kernels live in gemm.hip / attention.hip / elementwise.hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cellvit_amd.h"
+#include "attention.h"
+#include "elementwise.h"
+#include "gemm.h"
+
+static thread_local char g_err[1024] = "";
+void cva_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* cv_last_error(void) { return g_err; }
+
+using namespace cva;
+
+namespace {
+
+constexpr float LN_EPS = 1e-6f;   // cellvit.py:99, 559; SAM/utils.py:39
+constexpr double BN_EPS = 1e-5;   // torch default (utils.py:37, 80)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t esize(int dtype) { return dtype == CV_DTYPE_F16 ? 2 : 4; }
+inline int bk_of(int dtype) { return dtype == CV_DTYPE_F16 ? Traits<half_t>::BK : Traits<float>::BK; }
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+
+struct LinearW { void* W = nullptr; float* bias = nullptr; int N = 0, K = 0, ldw = 0; };
+struct ConvW { void* W = nullptr; float* bias = nullptr; int Cout = 0, Ctot = 0, K = 0, ldw = 0; int relu = 1; };
+struct ConvTW { void* W = nullptr; float* bias4 = nullptr; int Cin = 0, Cout = 0, ldw = 0; };
+struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
+struct HeadW { float* W = nullptr; float* b = nullptr; int n_out = 0; };
+struct BlockW {
+    LNW n1, n2; LinearW qkv, proj, fc1, fc2; bool global = true;
+    float* tab_h = nullptr; float* tab_w = nullptr;   // derived (geometry dependent)
+};
+struct BranchW {
+    ConvTW up4; ConvW d3[3]; ConvTW up3; ConvW d2[2]; ConvTW up2; ConvW d1[2]; ConvTW up1; ConvW d0[2]; HeadW head;
+};
+
+struct Geometry {
+    bool set = false;
+    int B = 0, H = 0, W = 0, gh = 0, gw = 0, P = 0, ntok = 0, has_cls = 0;
+    int nwy = 0, nwx = 0, Lw = 0, Lpw = 0, Lg = 0, Lpg = 0;
+};
+
+}  // namespace
+
+struct cv_handle {
+    cv_config cfg{};
+    bool finalized = false;
+    int debug = 0;
+    std::map<std::string, HostTensor> raw;
+    std::vector<void*> allocs;        // weights
+    std::vector<void*> ws_allocs;     // workspace (geometry dependent)
+    // packed weights
+    LinearW patch; float* cls_token = nullptr;
+    std::vector<BlockW> blocks;
+    LNW final_norm; LinearW vit_head;                 // ViT
+    LinearW neck0; LNW neck1; ConvW neck2; LNW neck3; LinearW cls_head;   // SAM
+    ConvW dec0[2];
+    ConvTW dec1_t[3]; ConvW dec1_c[3];
+    ConvTW dec2_t[2]; ConvW dec2_c[2];
+    ConvTW dec3_t[1]; ConvW dec3_c[1];
+    BranchW branch[3];
+    // geometry + workspace
+    Geometry g;
+    float* pos_table = nullptr;
+    void *patchA = nullptr, *xn = nullptr, *Q = nullptr, *K = nullptr, *Vt_win = nullptr, *Vt_glob = nullptr,
+         *attn_out = nullptr, *hidden = nullptr, *z[4] = {nullptr, nullptr, nullptr, nullptr}, *img8 = nullptr,
+         *skip[4] = {nullptr, nullptr, nullptr, nullptr}, *S[3] = {nullptr, nullptr, nullptr}, *small_T = nullptr;
+    float *resid = nullptr, *relh = nullptr, *relw = nullptr, *neck_f32a = nullptr, *neck_f32b = nullptr,
+          *small_f32 = nullptr, *dbg_blocks = nullptr, *dbg_tokens0 = nullptr;
+    size_t ws_bytes = 0;
+    int last_B = 0;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// allocation / upload helpers
+// ------------------------------------------------------------------------------------------------
+int dev_alloc(std::vector<void*>& pool, void** out, size_t bytes, bool zero = false) {
+    *out = nullptr;
+    if (bytes == 0) bytes = 16;
+    CVA_CHECK_HIP(hipMalloc(out, bytes));
+    pool.push_back(*out);
+    if (zero) CVA_CHECK_HIP(hipMemset(*out, 0, bytes));
+    return CV_OK;
+}
+
+int upload_f32(cv_handle* h, const float* src, size_t n, float** out) {
+    void* p;
+    int rc = dev_alloc(h->allocs, &p, n * sizeof(float));
+    if (rc) return rc;
+    CVA_CHECK_HIP(hipMemcpy(p, src, n * sizeof(float), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<float*>(p);
+    return CV_OK;
+}
+
+// rows x K fp32 host matrix -> device matrix of the compute dtype with row pitch ldw (zero padded)
+int upload_matrix(cv_handle* h, const float* src, int rows, int K, int ldw, void** out) {
+    const int dt = h->cfg.compute_dtype;
+    const size_t n = (size_t)rows * ldw;
+    void* p;
+    int rc = dev_alloc(h->allocs, &p, n * esize(dt));
+    if (rc) return rc;
+    if (dt == CV_DTYPE_F16) {
+        std::vector<half_t> tmp(n, (half_t)0.f);
+        for (int r = 0; r < rows; ++r)
+            for (int k = 0; k < K; ++k) tmp[(size_t)r * ldw + k] = (half_t)src[(size_t)r * K + k];
+        CVA_CHECK_HIP(hipMemcpy(p, tmp.data(), n * 2, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp(n, 0.f);
+        for (int r = 0; r < rows; ++r) memcpy(&tmp[(size_t)r * ldw], &src[(size_t)r * K], (size_t)K * 4);
+        CVA_CHECK_HIP(hipMemcpy(p, tmp.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    *out = p;
+    return CV_OK;
+}
+
+const HostTensor* find(cv_handle* h, const std::string& key, std::initializer_list<int64_t> shape) {
+    auto it = h->raw.find(key);
+    if (it == h->raw.end()) { cva_set_error("missing weight '%s'", key.c_str()); return nullptr; }
+    if (it->second.shape != std::vector<int64_t>(shape)) {
+        cva_set_error("weight '%s' has wrong shape", key.c_str());
+        return nullptr;
+    }
+    return &it->second;
+}
+
+#define CVA_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+#define CVA_NEED(ptr) do { if (!(ptr)) return CV_ERR_MISSING_WEIGHT; } while (0)
+
+int pack_linear(cv_handle* h, const std::string& p, int N, int K, bool bias, LinearW* out) {
+    const HostTensor* w = find(h, p + ".weight", {N, K});
+    CVA_NEED(w);
+    out->N = N; out->K = K; out->ldw = round_up(K, bk_of(h->cfg.compute_dtype));
+    CVA_TRY(upload_matrix(h, w->data.data(), N, K, out->ldw, &out->W));
+    if (bias) {
+        const HostTensor* b = find(h, p + ".bias", {N});
+        CVA_NEED(b);
+        CVA_TRY(upload_f32(h, b->data.data(), N, &out->bias));
+    }
+    return CV_OK;
+}
+
+int pack_ln(cv_handle* h, const std::string& p, int C, LNW* out) {
+    const HostTensor* g = find(h, p + ".weight", {C}); CVA_NEED(g);
+    const HostTensor* b = find(h, p + ".bias", {C}); CVA_NEED(b);
+    out->C = C;
+    CVA_TRY(upload_f32(h, g->data.data(), C, &out->g));
+    CVA_TRY(upload_f32(h, b->data.data(), C, &out->b));
+    return CV_OK;
+}
+
+// Conv2d 3x3 [Cout, Cin, 3, 3] (+bias) (+BatchNorm2d eval) -> [Cout, 9*Cpad], k = tap*Cpad + c.
+// conv_key / bn_key: full module prefixes; bn_key empty = no BN; has_bias false = no conv bias.
+int pack_conv3(cv_handle* h, const std::string& conv_key, const std::string& bn_key, int Cin, int Cout, int Cpad,
+               bool has_bias, int relu, ConvW* out) {
+    const HostTensor* w = find(h, conv_key + ".weight", {Cout, Cin, 3, 3}); CVA_NEED(w);
+    const HostTensor* cb = nullptr;
+    if (has_bias) { cb = find(h, conv_key + ".bias", {Cout}); CVA_NEED(cb); }
+    const HostTensor *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
+    if (!bn_key.empty()) {
+        g = find(h, bn_key + ".weight", {Cout}); CVA_NEED(g);
+        be = find(h, bn_key + ".bias", {Cout}); CVA_NEED(be);
+        mu = find(h, bn_key + ".running_mean", {Cout}); CVA_NEED(mu);
+        var = find(h, bn_key + ".running_var", {Cout}); CVA_NEED(var);
+    }
+    const int K = 9 * Cpad;
+    std::vector<float> wk((size_t)Cout * K, 0.f), bias(Cout, 0.f);
+    for (int co = 0; co < Cout; ++co) {
+        double scale = 1.0, shift = 0.0;
+        if (g) {
+            scale = (double)g->data[co] / std::sqrt((double)var->data[co] + BN_EPS);
+            shift = (double)be->data[co] - (double)mu->data[co] * scale;
+        }
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < 9; ++t)
+                wk[(size_t)co * K + t * Cpad + ci] = (float)((double)w->data[((size_t)co * Cin + ci) * 9 + t] * scale);
+        bias[co] = (float)((cb ? (double)cb->data[co] : 0.0) * scale + shift);
+    }
+    out->Cout = Cout; out->Ctot = Cpad; out->K = K; out->relu = relu;
+    out->ldw = round_up(K, bk_of(h->cfg.compute_dtype));
+    CVA_TRY(upload_matrix(h, wk.data(), Cout, K, out->ldw, &out->W));
+    if (has_bias || g) CVA_TRY(upload_f32(h, bias.data(), Cout, &out->bias));
+    return CV_OK;
+}
+
+// ConvTranspose2d k2 s2 [Cin, Cout, 2, 2] -> [4*Cout, Cin], n = (dy*2+dx)*Cout + co
+int pack_convT(cv_handle* h, const std::string& key, int Cin, int Cout, ConvTW* out) {
+    const HostTensor* w = find(h, key + ".weight", {Cin, Cout, 2, 2}); CVA_NEED(w);
+    const HostTensor* b = find(h, key + ".bias", {Cout}); CVA_NEED(b);
+    std::vector<float> wk((size_t)4 * Cout * Cin), b4((size_t)4 * Cout);
+    for (int dd = 0; dd < 4; ++dd)
+        for (int co = 0; co < Cout; ++co) {
+            b4[(size_t)dd * Cout + co] = b->data[co];
+            for (int ci = 0; ci < Cin; ++ci)
+                wk[((size_t)dd * Cout + co) * Cin + ci] = w->data[((size_t)ci * Cout + co) * 4 + dd];
+        }
+    out->Cin = Cin; out->Cout = Cout; out->ldw = round_up(Cin, bk_of(h->cfg.compute_dtype));
+    CVA_TRY(upload_matrix(h, wk.data(), 4 * Cout, Cin, out->ldw, &out->W));
+    CVA_TRY(upload_f32(h, b4.data(), (size_t)4 * Cout, &out->bias4));
+    return CV_OK;
+}
+
+int pack_conv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvW* out, int Cpad = 0) {
+    return pack_conv3(h, p + ".block.0", p + ".block.1", Cin, Cout, Cpad ? Cpad : Cin, true, 1, out);
+}
+int pack_deconv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvTW* t, ConvW* c) {
+    CVA_TRY(pack_convT(h, p + ".block.0", Cin, Cout, t));
+    return pack_conv3(h, p + ".block.1", p + ".block.2", Cout, Cout, Cout, true, 1, c);
+}
+
+void skip_dims(const cv_config& c, int* s11, int* s12, int* bott) {   // cellvit.py:106-113
+    if (c.embed_dim < 512) { *s11 = 256; *s12 = 128; *bott = 312; } else { *s11 = 512; *s12 = 256; *bott = 512; }
+}
+
+int pack_branch(cv_handle* h, const std::string& p, int n_out, BranchW* b) {
+    const int D = h->cfg.embed_dim;
+    int s11, s12, bott; skip_dims(h->cfg, &s11, &s12, &bott);
+    CVA_TRY(pack_convT(h, p + ".bottleneck_upsampler", D, bott, &b->up4));
+    CVA_TRY(pack_conv_block(h, p + ".decoder3_upsampler.0", 2 * bott, bott, &b->d3[0]));
+    CVA_TRY(pack_conv_block(h, p + ".decoder3_upsampler.1", bott, bott, &b->d3[1]));
+    CVA_TRY(pack_conv_block(h, p + ".decoder3_upsampler.2", bott, bott, &b->d3[2]));
+    CVA_TRY(pack_convT(h, p + ".decoder3_upsampler.3", bott, 256, &b->up3));
+    CVA_TRY(pack_conv_block(h, p + ".decoder2_upsampler.0", 512, 256, &b->d2[0]));
+    CVA_TRY(pack_conv_block(h, p + ".decoder2_upsampler.1", 256, 256, &b->d2[1]));
+    CVA_TRY(pack_convT(h, p + ".decoder2_upsampler.2", 256, 128, &b->up2));
+    CVA_TRY(pack_conv_block(h, p + ".decoder1_upsampler.0", 256, 128, &b->d1[0]));
+    CVA_TRY(pack_conv_block(h, p + ".decoder1_upsampler.1", 128, 128, &b->d1[1]));
+    CVA_TRY(pack_convT(h, p + ".decoder1_upsampler.2", 128, 64, &b->up1));
+    CVA_TRY(pack_conv_block(h, p + ".decoder0_header.0", 128, 64, &b->d0[0]));
+    CVA_TRY(pack_conv_block(h, p + ".decoder0_header.1", 64, 64, &b->d0[1]));
+    const HostTensor* w = find(h, p + ".decoder0_header.2.weight", {n_out, 64, 1, 1}); CVA_NEED(w);
+    const HostTensor* bb = find(h, p + ".decoder0_header.2.bias", {n_out}); CVA_NEED(bb);
+    b->head.n_out = n_out;
+    CVA_TRY(upload_f32(h, w->data.data(), (size_t)n_out * 64, &b->head.W));
+    CVA_TRY(upload_f32(h, bb->data.data(), n_out, &b->head.b));
+    return CV_OK;
+}
+
+bool is_global(const cv_config& c, int i) {
+    if (c.arch != CV_ARCH_SAM) return true;
+    for (int j = 0; j < c.n_global; ++j) if (c.global_attn_indexes[j] == i) return true;
+    return false;
+}
+
+void free_pool(std::vector<void*>& pool) {
+    for (void* p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+int run_linear(const void* A, int lda, const LinearW& w, const float* res, int ldres, int res_mod, void* out,
+               int ldc, int out_f32, int M, int act, hipStream_t st, int o_rpi = 0, int o_extra = 0, int o_off = 0) {
+    GemmParams p{};
+    p.M = M; p.N = w.N; p.K = w.K; p.A = A; p.W = w.W; p.lda = lda; p.ldw = w.ldw;
+    p.bias = w.bias; p.act = act; p.res = res; p.ldres = ldres; p.res_mod = res_mod;
+    p.out_mode = OUT_LINEAR; p.out_f32 = out_f32; p.out = out; p.ldc = ldc;
+    p.o_rpi = o_rpi; p.o_extra = o_extra; p.o_off = o_off;
+    const int rc = launch_gemm<T>(p, A_LINEAR, st);
+    if (rc) { cva_set_error("gemm launch failed (%d)", rc); return CV_ERR_HIP; }
+    return CV_OK;
+}
+
+template <typename T>
+int run_conv3(const void* s1, int C1, const void* s2, int C2, const ConvW& w, void* out, int out_f32, int B, int Hs,
+              int Ws, hipStream_t st) {
+    if (C1 + C2 != w.Ctot) { cva_set_error("conv3x3 channel mismatch %d+%d vs %d", C1, C2, w.Ctot); return CV_ERR_INVALID; }
+    GemmParams p{};
+    p.M = B * Hs * Ws; p.N = w.Cout; p.K = w.K; p.A = s1; p.A2 = s2; p.W = w.W; p.ldw = w.ldw;
+    p.H = Hs; p.Wd = Ws; p.C1 = C1; p.C2 = C2;
+    p.bias = w.bias; p.act = w.relu ? ACT_RELU : ACT_NONE;
+    p.out_mode = OUT_LINEAR; p.out_f32 = out_f32; p.out = out; p.ldc = w.Cout;
+    const int rc = launch_gemm<T>(p, A_CONV3, st);
+    if (rc) { cva_set_error("conv3x3 launch failed (%d)", rc); return CV_ERR_HIP; }
+    return CV_OK;
+}
+
+template <typename T>
+int run_convT(const void* src, const ConvTW& w, void* out, int B, int Hs, int Ws, hipStream_t st) {
+    GemmParams p{};
+    p.M = B * Hs * Ws; p.N = 4 * w.Cout; p.K = w.Cin; p.A = src; p.W = w.W; p.lda = w.Cin; p.ldw = w.ldw;
+    p.H = Hs; p.Wd = Ws;
+    p.bias = w.bias4; p.act = ACT_NONE; p.out_mode = OUT_CONVT; p.out_f32 = 0; p.out = out;
+    const int rc = launch_gemm<T>(p, A_LINEAR, st);
+    if (rc) { cva_set_error("convT launch failed (%d)", rc); return CV_ERR_HIP; }
+    return CV_OK;
+}
+
+#define CVA_LAUNCH(expr) do { int _rc = (expr); if (_rc) { cva_set_error("%s failed (%d)", #expr, _rc); return CV_ERR_HIP; } } while (0)
+
+// One attention layer on normalised token rows xn[B*ntok, D] -> attn_out[B*ntok, D].
+template <typename T>
+int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, const float* tab_w, bool window,
+                        void* Q, void* K, void* Vt, float* relh, float* relw, void* attn_out, int B, int gh, int gw,
+                        int has_cls, int heads, int D, int ws, hipStream_t st) {
+    const int hd = D / heads, P = gh * gw, ntok = P + has_cls;
+    const int nwy = window ? (gh + ws - 1) / ws : 0, nwx = window ? (gw + ws - 1) / ws : 0;
+    const int L = window ? ws * ws : ntok, Lp = round_up(L, 64);
+    const int S = window ? B * nwy * nwx : B;
+    GemmParams g{};
+    g.M = B * ntok; g.N = 3 * D; g.K = D; g.A = xn; g.W = qkv.W; g.lda = D; g.ldw = qkv.ldw;
+    g.bias = qkv.bias; g.act = ACT_NONE; g.out_mode = OUT_QKV;
+    g.q_out = Q; g.k_out = K; g.vt_out = Vt;
+    g.D = D; g.hd = hd; g.heads = heads; g.ntok = ntok; g.L = L; g.Lp = Lp;
+    g.win = window ? ws : 0; g.gw = gw; g.gh = gh; g.nwx = nwx; g.nwy = nwy;
+    CVA_LAUNCH(launch_gemm<T>(g, A_LINEAR, st));
+    if (window && (nwy * ws != gh || nwx * ws != gw)) {
+        PadKVParams pk{};
+        pk.K = K; pk.Vt = Vt; pk.qkv_bias = qkv.bias; pk.B = B; pk.heads = heads; pk.hd = hd; pk.D = D; pk.L = L;
+        pk.Lp = Lp; pk.win = ws; pk.gw = gw; pk.gh = gh; pk.nwx = nwx; pk.nwy = nwy;
+        CVA_LAUNCH(launch_pad_kv<T>(pk, st));
+    }
+    const int KH = window ? ws : gh, KW = window ? ws : gw;
+    if (tab_h) {
+        RelPosParams rp{};
+        rp.Q = Q; rp.tab_h = tab_h; rp.tab_w = tab_w; rp.relh = relh; rp.relw = relw;
+        rp.SH = S * heads; rp.L = L; rp.hd = hd; rp.KH = KH; rp.KW = KW;
+        CVA_LAUNCH(launch_relpos<T>(rp, st));
+    }
+    AttnParams a{};
+    a.Q = Q; a.K = K; a.Vt = Vt; a.relh = tab_h ? relh : nullptr; a.relw = tab_h ? relw : nullptr; a.out = attn_out;
+    a.S = S; a.heads = heads; a.L = L; a.Lp = Lp; a.hd = hd; a.D = D; a.nk = L; a.KH = KH; a.KW = KW;
+    a.scale = 1.0f / std::sqrt((float)hd);
+    a.ntok = ntok; a.win = window ? ws : 0; a.gw = gw; a.gh = gh; a.nwx = nwx; a.nwy = nwy;
+    CVA_LAUNCH(launch_attention<T>(a, st));
+    return CV_OK;
+}
+
+template <typename T>
+int forward_impl(cv_handle* h, const float* x, int B, const cv_outputs* out, hipStream_t st) {
+    const cv_config& c = h->cfg;
+    const Geometry& g = h->g;
+    const int D = c.embed_dim, heads = c.num_heads, H = g.H, W = g.W, P = g.P, ntok = g.ntok;
+    const int M = B * ntok, hid = D * c.mlp_ratio;
+    int s11, s12, bott; skip_dims(c, &s11, &s12, &bott);
+
+    // ---- patch embedding + positional table (F1/F2/F2') ----
+    CVA_LAUNCH(launch_patchify<T>(x, h->patchA, B, H, W, st));
+    CVA_TRY(run_linear<T>(h->patchA, 768, h->patch, h->pos_table + (size_t)g.has_cls * D, D, P, h->resid, D, 1,
+                          B * P, ACT_NONE, st, g.has_cls ? P : 0, g.has_cls, g.has_cls));
+    if (g.has_cls) CVA_LAUNCH(launch_cls_rows(h->cls_token, h->pos_table, h->resid, B, ntok, D, st));
+    if (h->debug) CVA_CHECK_HIP(hipMemcpyAsync(h->dbg_tokens0, h->resid, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+
+    // ---- transformer blocks (F3/F4/F5) ----
+    int zi = 0;
+    for (int i = 0; i < c.depth; ++i) {
+        const BlockW& b = h->blocks[i];
+        CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n1.g, b.n1.b, h->xn, 0, M, D, LN_EPS, st));
+        const bool window = !b.global;
+        CVA_TRY(run_attention_layer<T>(h->xn, b.qkv, b.tab_h, b.tab_w, window, h->Q, h->K,
+                                       window ? h->Vt_win : h->Vt_glob, h->relh, h->relw, h->attn_out, B, g.gh, g.gw,
+                                       g.has_cls, heads, D, c.window_size, st));
+        CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st));
+        CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n2.g, b.n2.b, h->xn, 0, M, D, LN_EPS, st));
+        CVA_TRY(run_linear<T>(h->xn, D, b.fc1, nullptr, 0, 0, h->hidden, hid, 0, M, ACT_GELU, st));
+        CVA_TRY(run_linear<T>(h->hidden, hid, b.fc2, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st));
+        if (h->debug)
+            CVA_CHECK_HIP(hipMemcpyAsync(h->dbg_blocks + (size_t)i * g.B * ntok * D, h->resid, (size_t)M * D * 4,
+                                         hipMemcpyDeviceToDevice, st));
+        for (int j = 0; j < 4; ++j) {
+            if (c.extract_layers[j] != i + 1) continue;
+            CVA_LAUNCH(launch_cast_tokens<T>(h->resid, h->z[j], B, ntok, g.has_cls, D, st));
+            if (j == 3 && out->tokens_nhwc)
+                CVA_LAUNCH(launch_cast_tokens<float>(h->resid, out->tokens_nhwc, B, ntok, g.has_cls, D, st));
+            ++zi;
+        }
+    }
+    if (zi != 4) { cva_set_error("extract_layers must name 4 distinct blocks"); return CV_ERR_INVALID; }
+
+    // ---- tissue-type head (F6) ----
+    if (out->tissue_types && c.num_tissue_classes > 0) {
+        if (c.arch == CV_ARCH_VIT) {
+            CVA_LAUNCH(launch_layernorm<T>(h->resid, (long)ntok * D, h->final_norm.g, h->final_norm.b, h->small_T, 0, B,
+                                           D, LN_EPS, st));
+            CVA_TRY(run_linear<T>(h->small_T, D, h->vit_head, nullptr, 0, 0, out->tissue_types, c.num_tissue_classes,
+                                  1, B, ACT_NONE, st));
+        } else {
+            const int C = c.neck_chans;
+            CVA_LAUNCH(launch_cast_tokens<T>(h->resid, h->xn, B, ntok, 0, D, st));
+            CVA_TRY(run_linear<T>(h->xn, D, h->neck0, nullptr, 0, 0, h->neck_f32a, C, 1, M, ACT_NONE, st));
+            CVA_LAUNCH(launch_layernorm<T>(h->neck_f32a, C, h->neck1.g, h->neck1.b, h->attn_out, 0, M, C, LN_EPS, st));
+            CVA_TRY(run_conv3<T>(h->attn_out, C, nullptr, 0, h->neck2, h->neck_f32a, 1, B, g.gh, g.gw, st));
+            CVA_LAUNCH(launch_layernorm<T>(h->neck_f32a, C, h->neck3.g, h->neck3.b, h->neck_f32b, 1, M, C, LN_EPS, st));
+            CVA_LAUNCH(launch_mean_rows(h->neck_f32b, h->small_f32, B, P, C, st));
+            CVA_LAUNCH(launch_cast<T>(h->small_f32, h->small_T, (long)B * C, st));
+            CVA_TRY(run_linear<T>(h->small_T, C, h->cls_head, nullptr, 0, 0, out->tissue_types, c.num_tissue_classes,
+                                  1, B, ACT_NONE, st));
+        }
+    }
+
+    // ---- shared skip decoders, evaluated ONCE (F9; the reference re-runs them per branch) ----
+    const int gh = g.gh, gw = g.gw;
+    void *S0 = h->S[0], *S1 = h->S[1], *S2 = h->S[2];
+    CVA_LAUNCH(launch_nchw3_to_nhwc8<T>(x, h->img8, B, H, W, st));
+    CVA_TRY(run_conv3<T>(h->img8, 8, nullptr, 0, h->dec0[0], S0, 0, B, H, W, st));
+    CVA_TRY(run_conv3<T>(S0, 32, nullptr, 0, h->dec0[1], h->skip[0], 0, B, H, W, st));
+    // decoder1: z1 -> x8
+    CVA_TRY(run_convT<T>(h->z[0], h->dec1_t[0], S0, B, gh, gw, st));
+    CVA_TRY(run_conv3<T>(S0, s11, nullptr, 0, h->dec1_c[0], S1, 0, B, 2 * gh, 2 * gw, st));
+    CVA_TRY(run_convT<T>(S1, h->dec1_t[1], S0, B, 2 * gh, 2 * gw, st));
+    CVA_TRY(run_conv3<T>(S0, s12, nullptr, 0, h->dec1_c[1], S1, 0, B, 4 * gh, 4 * gw, st));
+    CVA_TRY(run_convT<T>(S1, h->dec1_t[2], S0, B, 4 * gh, 4 * gw, st));
+    CVA_TRY(run_conv3<T>(S0, 128, nullptr, 0, h->dec1_c[2], h->skip[1], 0, B, 8 * gh, 8 * gw, st));
+    // decoder2: z2 -> x4
+    CVA_TRY(run_convT<T>(h->z[1], h->dec2_t[0], S0, B, gh, gw, st));
+    CVA_TRY(run_conv3<T>(S0, s11, nullptr, 0, h->dec2_c[0], S1, 0, B, 2 * gh, 2 * gw, st));
+    CVA_TRY(run_convT<T>(S1, h->dec2_t[1], S0, B, 2 * gh, 2 * gw, st));
+    CVA_TRY(run_conv3<T>(S0, 256, nullptr, 0, h->dec2_c[1], h->skip[2], 0, B, 4 * gh, 4 * gw, st));
+    // decoder3: z3 -> x2
+    CVA_TRY(run_convT<T>(h->z[2], h->dec3_t[0], S0, B, gh, gw, st));
+    CVA_TRY(run_conv3<T>(S0, bott, nullptr, 0, h->dec3_c[0], h->skip[3], 0, B, 2 * gh, 2 * gw, st));
+
+    // ---- three upsampling branches (F10), concat order [skip, upsampled] (cellvit.py:236-242) ----
+    for (int br = 0; br < 3; ++br) {
+        const BranchW& b = h->branch[br];
+        CVA_TRY(run_convT<T>(h->z[3], b.up4, S0, B, gh, gw, st));
+        CVA_TRY(run_conv3<T>(h->skip[3], bott, S0, bott, b.d3[0], S1, 0, B, 2 * gh, 2 * gw, st));
+        CVA_TRY(run_conv3<T>(S1, bott, nullptr, 0, b.d3[1], S2, 0, B, 2 * gh, 2 * gw, st));
+        CVA_TRY(run_conv3<T>(S2, bott, nullptr, 0, b.d3[2], S1, 0, B, 2 * gh, 2 * gw, st));
+        CVA_TRY(run_convT<T>(S1, b.up3, S0, B, 2 * gh, 2 * gw, st));
+        CVA_TRY(run_conv3<T>(h->skip[2], 256, S0, 256, b.d2[0], S1, 0, B, 4 * gh, 4 * gw, st));
+        CVA_TRY(run_conv3<T>(S1, 256, nullptr, 0, b.d2[1], S2, 0, B, 4 * gh, 4 * gw, st));
+        CVA_TRY(run_convT<T>(S2, b.up2, S0, B, 4 * gh, 4 * gw, st));
+        CVA_TRY(run_conv3<T>(h->skip[1], 128, S0, 128, b.d1[0], S1, 0, B, 8 * gh, 8 * gw, st));
+        CVA_TRY(run_conv3<T>(S1, 128, nullptr, 0, b.d1[1], S2, 0, B, 8 * gh, 8 * gw, st));
+        CVA_TRY(run_convT<T>(S2, b.up1, S0, B, 8 * gh, 8 * gw, st));
+        CVA_TRY(run_conv3<T>(h->skip[0], 64, S0, 64, b.d0[0], S1, 0, B, H, W, st));
+        CVA_TRY(run_conv3<T>(S1, 64, nullptr, 0, b.d0[1], S2, 0, B, H, W, st));
+        float* logits = br == 0 ? out->nuclei_binary_map : br == 1 ? out->hv_map : out->nuclei_type_map;
+        uint8_t* am = br == 0 ? out->binary_argmax : br == 2 ? out->type_argmax : nullptr;
+        const long npix = (long)H * W;
+        if (br == 0 && c.regression_loss) {
+            // binary branch carries 2 extra regression channels (cellvit.py:191-196): write the 4-channel
+            // result into the scratch logits and split on the fly is not needed — emit two heads.
+            HeadW h0 = b.head, h1 = b.head;
+            h0.n_out = 2; h1.n_out = 2; h1.W = b.head.W + 2 * 64; h1.b = b.head.b + 2;
+            if (logits) CVA_LAUNCH(launch_head1x1<T>(S2, h0.W, h0.b, logits, am, 2, npix, B, 2, st));
+            if (out->regression_map)
+                CVA_LAUNCH(launch_head1x1<T>(S2, h1.W, h1.b, out->regression_map, nullptr, 0, npix, B, 2, st));
+        } else if (logits) {
+            CVA_LAUNCH(launch_head1x1<T>(S2, b.head.W, b.head.b, logits, am, b.head.n_out, npix, B, b.head.n_out, st));
+        }
+    }
+    h->last_B = B;
+    return CV_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" int cv_create(const cv_config* cfg, cv_handle** out) {
+    if (!cfg || !out) { cva_set_error("null argument"); return CV_ERR_INVALID; }
+    if (cfg->arch != CV_ARCH_VIT && cfg->arch != CV_ARCH_SAM) {
+        cva_set_error("Unknown ViT backbone structure");
+        return CV_ERR_UNSUPPORTED;
+    }
+    if (cfg->patch_size != 16 || cfg->embed_dim % cfg->num_heads != 0 || cfg->embed_dim % 64 != 0 ||
+        cfg->depth <= 0 || cfg->mlp_ratio <= 0 || cfg->n_global < 0 || cfg->n_global > 8) {
+        cva_set_error("unsupported configuration (patch 16, embed_dim %% 64 == 0 required)");
+        return CV_ERR_INVALID;
+    }
+    const int hd = cfg->embed_dim / cfg->num_heads;
+    if (hd != 64 && hd != 80) { cva_set_error("head_dim %d not built (64, 80)", hd); return CV_ERR_UNSUPPORTED; }
+    if (cfg->compute_dtype != CV_DTYPE_F16 && cfg->compute_dtype != CV_DTYPE_F32) {
+        cva_set_error("bad compute_dtype"); return CV_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        cva_set_error("no HIP device visible: the cellvit_amd hot path has no CPU fallback");
+        return CV_ERR_HIP;
+    }
+    cv_handle* h = new cv_handle();
+    h->cfg = *cfg;
+    *out = h;
+    return CV_OK;
+}
+
+extern "C" int cv_destroy(cv_handle* h) {
+    if (!h) return CV_OK;
+    free_pool(h->allocs);
+    free_pool(h->ws_allocs);
+    delete h;
+    return CV_OK;
+}
+
+extern "C" int cv_load_weight(cv_handle* h, const char* key, const void* host_ptr, int dtype, const int64_t* shape,
+                              int ndim) {
+    if (!h || !key || !host_ptr || ndim < 0 || ndim > 8) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    if (h->finalized) { cva_set_error("cv_load_weight after cv_finalize"); return CV_ERR_STATE; }
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    const size_t n = t.numel();
+    if (dtype == 1) {
+        t.data.assign(reinterpret_cast<const float*>(host_ptr), reinterpret_cast<const float*>(host_ptr) + n);
+    } else if (dtype == 2) {
+        t.data.resize(n);
+        for (size_t i = 0; i < n; ++i) t.data[i] = (float)reinterpret_cast<const int64_t*>(host_ptr)[i];
+    } else { cva_set_error("dtype must be 1 (f32) or 2 (i64)"); return CV_ERR_INVALID; }
+    h->raw[key] = std::move(t);
+    return CV_OK;
+}
+
+extern "C" int cv_finalize(cv_handle* h) {
+    if (!h) return CV_ERR_INVALID;
+    if (h->finalized) return CV_OK;
+    const cv_config& c = h->cfg;
+    const int D = c.embed_dim, hid = D * c.mlp_ratio;
+    int s11, s12, bott; skip_dims(c, &s11, &s12, &bott);
+    // patch embedding: Conv2d(3, D, 16, 16) weight flattens to the [D, 768] GEMM operand as is
+    {
+        const HostTensor* w = find(h, "encoder.patch_embed.proj.weight", {D, 3, 16, 16}); CVA_NEED(w);
+        const HostTensor* b = find(h, "encoder.patch_embed.proj.bias", {D}); CVA_NEED(b);
+        h->patch.N = D; h->patch.K = 768; h->patch.ldw = round_up(768, bk_of(c.compute_dtype));
+        CVA_TRY(upload_matrix(h, w->data.data(), D, 768, h->patch.ldw, &h->patch.W));
+        CVA_TRY(upload_f32(h, b->data.data(), D, &h->patch.bias));
+    }
+    if (c.arch == CV_ARCH_VIT) {
+        const HostTensor* cls = find(h, "encoder.cls_token", {1, 1, D}); CVA_NEED(cls);
+        CVA_TRY(upload_f32(h, cls->data.data(), D, &h->cls_token));
+    }
+    h->blocks.resize(c.depth);
+    for (int i = 0; i < c.depth; ++i) {
+        const std::string p = "encoder.blocks." + std::to_string(i);
+        BlockW& b = h->blocks[i];
+        b.global = is_global(c, i);
+        CVA_TRY(pack_ln(h, p + ".norm1", D, &b.n1));
+        CVA_TRY(pack_linear(h, p + ".attn.qkv", 3 * D, D, true, &b.qkv));
+        CVA_TRY(pack_linear(h, p + ".attn.proj", D, D, true, &b.proj));
+        CVA_TRY(pack_ln(h, p + ".norm2", D, &b.n2));
+        const char* f1 = c.arch == CV_ARCH_VIT ? ".mlp.fc1" : ".mlp.lin1";
+        const char* f2 = c.arch == CV_ARCH_VIT ? ".mlp.fc2" : ".mlp.lin2";
+        CVA_TRY(pack_linear(h, p + f1, hid, D, true, &b.fc1));
+        CVA_TRY(pack_linear(h, p + f2, D, hid, true, &b.fc2));
+    }
+    if (c.arch == CV_ARCH_VIT) {
+        CVA_TRY(pack_ln(h, "encoder.norm", D, &h->final_norm));
+        if (c.num_tissue_classes > 0) CVA_TRY(pack_linear(h, "encoder.head", c.num_tissue_classes, D, true, &h->vit_head));
+    } else {
+        const int C = c.neck_chans;
+        const HostTensor* w = find(h, "encoder.neck.0.weight", {C, D, 1, 1}); CVA_NEED(w);
+        h->neck0.N = C; h->neck0.K = D; h->neck0.ldw = round_up(D, bk_of(c.compute_dtype));
+        CVA_TRY(upload_matrix(h, w->data.data(), C, D, h->neck0.ldw, &h->neck0.W));
+        CVA_TRY(pack_ln(h, "encoder.neck.1", C, &h->neck1));
+        CVA_TRY(pack_conv3(h, "encoder.neck.2", "", C, C, C, false, 0, &h->neck2));
+        CVA_TRY(pack_ln(h, "encoder.neck.3", C, &h->neck3));
+        if (c.num_tissue_classes > 0) CVA_TRY(pack_linear(h, "classifier_head", c.num_tissue_classes, C, true, &h->cls_head));
+    }
+    // shared skip decoders (cellvit.py:116-131)
+    CVA_TRY(pack_conv_block(h, "decoder0.0", 3, 32, &h->dec0[0], 8));
+    CVA_TRY(pack_conv_block(h, "decoder0.1", 32, 64, &h->dec0[1]));
+    CVA_TRY(pack_deconv_block(h, "decoder1.0", D, s11, &h->dec1_t[0], &h->dec1_c[0]));
+    CVA_TRY(pack_deconv_block(h, "decoder1.1", s11, s12, &h->dec1_t[1], &h->dec1_c[1]));
+    CVA_TRY(pack_deconv_block(h, "decoder1.2", s12, 128, &h->dec1_t[2], &h->dec1_c[2]));
+    CVA_TRY(pack_deconv_block(h, "decoder2.0", D, s11, &h->dec2_t[0], &h->dec2_c[0]));
+    CVA_TRY(pack_deconv_block(h, "decoder2.1", s11, 256, &h->dec2_t[1], &h->dec2_c[1]));
+    CVA_TRY(pack_deconv_block(h, "decoder3.0", D, bott, &h->dec3_t[0], &h->dec3_c[0]));
+    const int nb = 2 + (c.regression_loss ? 2 : 0);
+    CVA_TRY(pack_branch(h, "nuclei_binary_map_decoder", nb, &h->branch[0]));
+    CVA_TRY(pack_branch(h, "hv_map_decoder", 2, &h->branch[1]));
+    CVA_TRY(pack_branch(h, "nuclei_type_maps_decoder", c.num_nuclei_classes, &h->branch[2]));
+    // keep pos_embed / rel_pos raw tensors for callers that query them; drop the bulk of host copies
+    std::map<std::string, HostTensor> keep;
+    for (auto& kv : h->raw)
+        if (kv.first.find("pos_embed") != std::string::npos || kv.first.find("rel_pos") != std::string::npos)
+            keep[kv.first] = std::move(kv.second);
+    h->raw.swap(keep);
+    CVA_CHECK_HIP(hipDeviceSynchronize());
+    h->finalized = true;
+    return CV_OK;
+}
+
+extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
+    if (!h || max_batch <= 0) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    if (!h->finalized) { cva_set_error("cv_set_geometry before cv_finalize"); return CV_ERR_STATE; }
+    const cv_config& c = h->cfg;
+    if (H <= 0 || W <= 0 || H % c.patch_size != 0 || W % c.patch_size != 0) {
+        cva_set_error("Img must have a shape of that is divisible by patch_size (token_size)");
+        return CV_ERR_SHAPE;
+    }
+    Geometry g;
+    g.B = max_batch; g.H = H; g.W = W; g.gh = H / 16; g.gw = W / 16; g.P = g.gh * g.gw;
+    g.has_cls = c.arch == CV_ARCH_VIT ? 1 : 0;
+    g.ntok = g.P + g.has_cls;
+    if (c.arch == CV_ARCH_SAM) {
+        if (g.gh > 64 || g.gw > 64) { cva_set_error("SAM encoder: tiles larger than 1024 px are not supported"); return CV_ERR_UNSUPPORTED; }
+        const int ws = c.window_size;
+        g.nwy = (g.gh + ws - 1) / ws; g.nwx = (g.gw + ws - 1) / ws; g.Lw = ws * ws; g.Lpw = round_up(g.Lw, 64);
+    }
+    g.Lg = g.ntok; g.Lpg = round_up(g.Lg, 64);
+    free_pool(h->ws_allocs);
+    h->ws_bytes = 0;
+    for (auto& b : h->blocks) { b.tab_h = b.tab_w = nullptr; }
+    h->pos_table = nullptr;
+
+    const int dt = c.compute_dtype;
+    const size_t es = esize(dt);
+    const int D = c.embed_dim, heads = c.num_heads, hd = D / heads, B = g.B;
+    const size_t M = (size_t)B * g.ntok;
+    int s11, s12, bott; skip_dims(c, &s11, &s12, &bott);
+    auto A = [&](void** p, size_t bytes, bool zero = false) -> int {
+        h->ws_bytes += bytes;
+        return dev_alloc(h->ws_allocs, p, bytes, zero);
+    };
+    CVA_TRY(A(&h->patchA, (size_t)B * g.P * 768 * es));
+    CVA_TRY(A((void**)&h->resid, M * D * 4));
+    CVA_TRY(A(&h->xn, M * D * es));
+    const size_t nwin = (size_t)g.nwy * g.nwx;
+    const size_t qk_elems = std::max((size_t)B * heads * g.Lg * hd, (size_t)B * nwin * heads * g.Lw * hd);
+    CVA_TRY(A(&h->Q, qk_elems * es, true));
+    CVA_TRY(A(&h->K, qk_elems * es, true));
+    CVA_TRY(A(&h->Vt_glob, (size_t)B * heads * hd * g.Lpg * es, true));
+    if (c.arch == CV_ARCH_SAM) {
+        CVA_TRY(A(&h->Vt_win, (size_t)B * nwin * heads * hd * g.Lpw * es, true));
+        const size_t rel_h = std::max((size_t)B * heads * g.Lg * g.gh, (size_t)B * nwin * heads * g.Lw * c.window_size);
+        const size_t rel_w = std::max((size_t)B * heads * g.Lg * g.gw, (size_t)B * nwin * heads * g.Lw * c.window_size);
+        CVA_TRY(A((void**)&h->relh, rel_h * 4));
+        CVA_TRY(A((void**)&h->relw, rel_w * 4));
+        CVA_TRY(A((void**)&h->neck_f32a, M * c.neck_chans * 4));
+        CVA_TRY(A((void**)&h->neck_f32b, M * c.neck_chans * 4));
+    }
+    CVA_TRY(A(&h->attn_out, M * D * es));
+    CVA_TRY(A(&h->hidden, M * D * c.mlp_ratio * es));
+    for (int j = 0; j < 4; ++j) CVA_TRY(A(&h->z[j], (size_t)B * g.P * D * es));
+    CVA_TRY(A(&h->img8, (size_t)B * H * W * 8 * es));
+    const size_t hw = (size_t)H * W;
+    CVA_TRY(A(&h->skip[0], (size_t)B * hw * 64 * es));
+    CVA_TRY(A(&h->skip[1], (size_t)B * hw / 4 * 128 * es));
+    CVA_TRY(A(&h->skip[2], (size_t)B * hw / 16 * 256 * es));
+    CVA_TRY(A(&h->skip[3], (size_t)B * hw / 64 * bott * es));
+    // scratch: the widest intermediate is 64 channels at full resolution (or s11/bott at 1/8)
+    size_t smax = hw * 64;
+    smax = std::max(smax, hw / 64 * (size_t)std::max(s11, bott));
+    smax = std::max(smax, hw / 16 * (size_t)std::max(s12, 256));
+    smax = std::max(smax, hw / 4 * (size_t)128);
+    for (int j = 0; j < 3; ++j) CVA_TRY(A(&h->S[j], (size_t)B * smax * es));
+    const size_t small = (size_t)B * std::max(D, c.neck_chans);
+    CVA_TRY(A(&h->small_T, small * es));
+    CVA_TRY(A((void**)&h->small_f32, small * 4));
+    if (h->debug) {
+        CVA_TRY(A((void**)&h->dbg_blocks, (size_t)c.depth * M * D * 4));
+        CVA_TRY(A((void**)&h->dbg_tokens0, M * D * 4));
+    }
+    g.set = true;
+    h->g = g;
+    return CV_OK;
+}
+
+extern "C" int cv_set_derived(cv_handle* h, const char* name, const float* host_ptr, const int64_t* shape, int ndim) {
+    if (!h || !name || !host_ptr || ndim != 2) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    if (!h->g.set) { cva_set_error("cv_set_derived before cv_set_geometry"); return CV_ERR_STATE; }
+    const cv_config& c = h->cfg;
+    const int D = c.embed_dim, hd = D / c.num_heads;
+    const size_t n = (size_t)shape[0] * shape[1];
+    float* dev = nullptr;
+    const std::string s(name);
+    auto up = [&]() -> int {
+        void* p;
+        CVA_TRY(dev_alloc(h->ws_allocs, &p, n * 4));
+        CVA_CHECK_HIP(hipMemcpy(p, host_ptr, n * 4, hipMemcpyHostToDevice));
+        dev = reinterpret_cast<float*>(p);
+        return CV_OK;
+    };
+    if (s == "pos_table") {
+        if (shape[0] != h->g.ntok || shape[1] != D) { cva_set_error("pos_table must be [%d, %d]", h->g.ntok, D); return CV_ERR_INVALID; }
+        CVA_TRY(up());
+        h->pos_table = dev;
+        return CV_OK;
+    }
+    if (s.rfind("rel_h.", 0) == 0 || s.rfind("rel_w.", 0) == 0) {
+        const int i = atoi(s.c_str() + 6);
+        if (c.arch != CV_ARCH_SAM || i < 0 || i >= c.depth) { cva_set_error("bad block index in '%s'", name); return CV_ERR_INVALID; }
+        const bool is_h = s[4] == 'h';
+        const int side = h->blocks[i].global ? (is_h ? h->g.gh : h->g.gw) : c.window_size;
+        if (shape[0] != 2 * side - 1 || shape[1] != hd) { cva_set_error("'%s' must be [%d, %d]", name, 2 * side - 1, hd); return CV_ERR_INVALID; }
+        CVA_TRY(up());
+        (is_h ? h->blocks[i].tab_h : h->blocks[i].tab_w) = dev;
+        return CV_OK;
+    }
+    cva_set_error("unknown derived tensor '%s'", name);
+    return CV_ERR_INVALID;
+}
+
+extern "C" int cv_forward(cv_handle* h, const float* x_dev, int B, int H, int W, const cv_outputs* out, void* stream) {
+    if (!h || !x_dev || !out) { cva_set_error("null argument"); return CV_ERR_INVALID; }
+    if (!h->finalized) { cva_set_error("cv_forward before cv_finalize"); return CV_ERR_STATE; }
+    if (H % h->cfg.patch_size != 0 || W % h->cfg.patch_size != 0) {
+        cva_set_error("Img must have a shape of that is divisible by patch_size (token_size)");
+        return CV_ERR_SHAPE;
+    }
+    if (!h->g.set || h->g.H != H || h->g.W != W || B > h->g.B || B <= 0) {
+        cva_set_error("geometry not set for B=%d H=%d W=%d (call cv_set_geometry)", B, H, W);
+        return CV_ERR_STATE;
+    }
+    if (!h->pos_table) { cva_set_error("derived tensor 'pos_table' not set"); return CV_ERR_STATE; }
+    if (h->cfg.arch == CV_ARCH_SAM)
+        for (int i = 0; i < h->cfg.depth; ++i)
+            if (!h->blocks[i].tab_h || !h->blocks[i].tab_w) { cva_set_error("derived rel-pos tables of block %d not set", i); return CV_ERR_STATE; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return h->cfg.compute_dtype == CV_DTYPE_F16 ? forward_impl<half_t>(h, x_dev, B, out, st)
+                                                 : forward_impl<float>(h, x_dev, B, out, st);
+}
+
+extern "C" int cv_set_debug(cv_handle* h, int enable) {
+    if (!h) return CV_ERR_INVALID;
+    if (h->g.set && enable && !h->debug) { cva_set_error("cv_set_debug must precede cv_set_geometry"); return CV_ERR_STATE; }
+    h->debug = enable;
+    return CV_OK;
+}
+
+namespace {
+template <typename T> __global__ void to_f32_kernel(const T* in, float* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+}  // namespace
+
+extern "C" int cv_debug_read(cv_handle* h, const char* name, float* host_dst, size_t capacity, size_t* n_out) {
+    if (!h || !name || !host_dst || !h->g.set || h->last_B <= 0) { cva_set_error("nothing to read"); return CV_ERR_STATE; }
+    const cv_config& c = h->cfg; const Geometry& g = h->g;
+    const int B = h->last_B, D = c.embed_dim;
+    int s11, s12, bott; skip_dims(c, &s11, &s12, &bott);
+    const std::string s(name);
+    const void* src = nullptr; size_t n = 0; bool is_T = true;
+    const size_t hw = (size_t)g.H * g.W;
+    if (s == "tokens0" && h->debug) { src = h->dbg_tokens0; n = (size_t)B * g.ntok * D; is_T = false; }
+    else if (s.rfind("block", 0) == 0 && h->debug) {
+        const int i = atoi(s.c_str() + 5);
+        if (i < 0 || i >= c.depth) { cva_set_error("bad block"); return CV_ERR_INVALID; }
+        src = h->dbg_blocks + (size_t)i * g.B * g.ntok * D; n = (size_t)B * g.ntok * D; is_T = false;
+    } else if (s.size() == 2 && s[0] == 'z' && s[1] >= '1' && s[1] <= '4') { src = h->z[s[1] - '1']; n = (size_t)B * g.P * D; }
+    else if (s == "skip0") { src = h->skip[0]; n = B * hw * 64; }
+    else if (s == "skip1") { src = h->skip[1]; n = B * hw / 4 * 128; }
+    else if (s == "skip2") { src = h->skip[2]; n = B * hw / 16 * 256; }
+    else if (s == "skip3") { src = h->skip[3]; n = B * hw / 64 * bott; }
+    else { cva_set_error("unknown tap '%s' (debug=%d)", name, h->debug); return CV_ERR_INVALID; }
+    if (n_out) *n_out = n;
+    if (n > capacity) { cva_set_error("capacity too small: need %zu", n); return CV_ERR_INVALID; }
+    CVA_CHECK_HIP(hipDeviceSynchronize());
+    if (!is_T || c.compute_dtype == CV_DTYPE_F32) {
+        CVA_CHECK_HIP(hipMemcpy(host_dst, src, n * 4, hipMemcpyDeviceToHost));
+    } else {
+        float* tmp;
+        CVA_CHECK_HIP(hipMalloc((void**)&tmp, n * 4));
+        hipLaunchKernelGGL((to_f32_kernel<half_t>), dim3(1024), dim3(256), 0, 0, reinterpret_cast<const half_t*>(src), tmp, n);
+        CVA_CHECK_HIP(hipMemcpy(host_dst, tmp, n * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(tmp);
+    }
+    return CV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-operator entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int cv_op_linear(int dtype, const void* A, const void* W, const float* bias, const float* residual,
+                            void* out, int out_f32, int M, int N, int K, int act, void* stream) {
+    const int pe = dtype == CV_DTYPE_F16 ? 8 : 4;
+    if (K % pe != 0) { cva_set_error("K must be a multiple of %d", pe); return CV_ERR_INVALID; }
+    LinearW w; w.W = const_cast<void*>(W); w.bias = const_cast<float*>(bias); w.N = N; w.K = K; w.ldw = K;
+    // W rows are read in whole 16-B pieces below K only (pieces past K are predicated off for A and
+    // multiply zero), so an un-padded [N, K] matrix is safe here when K is a multiple of the tile row.
+    if (K % bk_of(dtype) != 0) { cva_set_error("cv_op_linear: K must be a multiple of %d", bk_of(dtype)); return CV_ERR_INVALID; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == CV_DTYPE_F16 ? run_linear<half_t>(A, K, w, residual, N, 0, out, N, out_f32, M, act, st)
+                                 : run_linear<float>(A, K, w, residual, N, 0, out, N, out_f32, M, act, st);
+}
+
+extern "C" int cv_op_layernorm(int dtype, const float* x, const float* gamma, const float* beta, void* out, int out_f32,
+                               int M, int C, float eps, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rc = dtype == CV_DTYPE_F16 ? launch_layernorm<half_t>(x, C, gamma, beta, out, out_f32, M, C, eps, st)
+                                         : launch_layernorm<float>(x, C, gamma, beta, out, out_f32, M, C, eps, st);
+    if (rc) { cva_set_error("layernorm launch failed (%d)", rc); return CV_ERR_HIP; }
+    return CV_OK;
+}
+
+extern "C" int cv_op_conv3x3(int dtype, const void* src1, int C1, const void* src2, int C2, const void* Wk,
+                             const float* bias, void* out, int out_f32, int B, int H, int W, int Cout, int relu,
+                             void* stream) {
+    const int pe = dtype == CV_DTYPE_F16 ? 8 : 4;
+    const int K = 9 * (C1 + C2);
+    if (C1 % pe || C2 % pe || K % bk_of(dtype)) { cva_set_error("cv_op_conv3x3: channels %% %d, 9*C %% %d required", pe, bk_of(dtype)); return CV_ERR_INVALID; }
+    ConvW w; w.W = const_cast<void*>(Wk); w.bias = const_cast<float*>(bias); w.Cout = Cout; w.Ctot = C1 + C2; w.K = K;
+    w.ldw = K; w.relu = relu;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == CV_DTYPE_F16 ? run_conv3<half_t>(src1, C1, src2, C2, w, out, out_f32, B, H, W, st)
+                                 : run_conv3<float>(src1, C1, src2, C2, w, out, out_f32, B, H, W, st);
+}
+
+extern "C" int cv_op_convT2x2(int dtype, const void* src, const void* Wk, const float* bias4, void* out, int B, int H,
+                              int W, int Cin, int Cout, void* stream) {
+    if (Cin % bk_of(dtype)) { cva_set_error("cv_op_convT2x2: Cin %% %d required", bk_of(dtype)); return CV_ERR_INVALID; }
+    ConvTW w; w.W = const_cast<void*>(Wk); w.bias4 = const_cast<float*>(bias4); w.Cin = Cin; w.Cout = Cout; w.ldw = Cin;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == CV_DTYPE_F16 ? run_convT<half_t>(src, w, out, B, H, W, st) : run_convT<float>(src, w, out, B, H, W, st);
+}
+
+extern "C" int cv_op_attention(int dtype, const void* x, const void* Wqkv, const float* bqkv, const float* tab_h,
+                               const float* tab_w, void* out, int B, int gh, int gw, int has_cls, int heads, int D,
+                               int win, void* stream) {
+    if (D % bk_of(dtype) || D % heads) { cva_set_error("cv_op_attention: bad D"); return CV_ERR_INVALID; }
+    const int hd = D / heads, P = gh * gw, ntok = P + has_cls;
+    const bool window = win > 0;
+    const int nwy = window ? (gh + win - 1) / win : 0, nwx = window ? (gw + win - 1) / win : 0;
+    const int L = window ? win * win : ntok, Lp = round_up(L, 64);
+    const size_t S = window ? (size_t)B * nwy * nwx : (size_t)B;
+    const size_t es = esize(dtype);
+    const int KH = window ? win : gh, KW = window ? win : gw;
+    std::vector<void*> pool;
+    void *Q, *K, *Vt; float *relh = nullptr, *relw = nullptr;
+    CVA_TRY(dev_alloc(pool, &Q, S * heads * L * hd * es, true));
+    CVA_TRY(dev_alloc(pool, &K, S * heads * L * hd * es, true));
+    CVA_TRY(dev_alloc(pool, &Vt, S * heads * hd * Lp * es, true));
+    if (tab_h) {
+        CVA_TRY(dev_alloc(pool, (void**)&relh, S * heads * L * KH * 4));
+        CVA_TRY(dev_alloc(pool, (void**)&relw, S * heads * L * KW * 4));
+    }
+    LinearW w; w.W = const_cast<void*>(Wqkv); w.bias = const_cast<float*>(bqkv); w.N = 3 * D; w.K = D; w.ldw = D;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = dtype == CV_DTYPE_F16
+                 ? run_attention_layer<half_t>(x, w, tab_h, tab_w, window, Q, K, Vt, relh, relw, out, B, gh, gw, has_cls, heads, D, win, st)
+                 : run_attention_layer<float>(x, w, tab_h, tab_w, window, Q, K, Vt, relh, relw, out, B, gh, gw, has_cls, heads, D, win, st);
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) { cva_set_error("attention: stream sync failed: %s", hipGetErrorString(hipGetLastError())); rc = CV_ERR_HIP; }
+    free_pool(pool);
+    return rc;
+}

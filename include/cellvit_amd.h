@@ -1,0 +1,134 @@
+/* cellvit_amd.h — C ABI of the MI355X-native CellViT inference hot path.
+ *
+ * The reference (TIO-IKIM/CellViT) is pure Python and has NO FFI / plugin layer: its seam is the
+ * nn.Module API.  Each entry point below cites the reference interface it replaces; the Python shim
+ * (cellvit_amd/model.py) and any other host (C, C++, cgo, JNI ...) bind exactly these symbols.
+ *
+ * Conventions
+ *   - every function returns an int status (CV_OK == 0); cv_last_error() gives the message.
+ *   - the CALLER owns all input/output device buffers (e.g. torch tensors); the library borrows the
+ *     pointers for the duration of the call and owns only its packed weights and workspace.
+ *   - work is enqueued on the caller's HIP stream (`stream` is a hipStream_t passed as void*;
+ *     NULL = default stream).  No hidden synchronisation except where a host-visible value is
+ *     returned (cv_postproc_* result counts, cv_debug_read).
+ *   - one handle per (process, device); a handle is not thread safe.
+ */
+#ifndef CELLVIT_AMD_H
+#define CELLVIT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    CV_OK = 0,
+    CV_ERR_INVALID = 1,      /* bad argument                                   -> ValueError          */
+    CV_ERR_HIP = 2,          /* HIP runtime failure                             -> RuntimeError        */
+    CV_ERR_STATE = 3,        /* call order (not finalized, geometry not set)    -> RuntimeError        */
+    CV_ERR_SHAPE = 4,        /* H or W not divisible by the patch size          -> AssertionError      */
+                             /*   (reference: cellvit.py:170-175, 603-608)                             */
+    CV_ERR_UNSUPPORTED = 5,  /* unknown arch / magnification                    -> NotImplementedError */
+                             /*   (reference: cellvit.py:530, post_proc_cellvit.py:61-62)              */
+    CV_ERR_MISSING_WEIGHT = 6/* state_dict key absent / wrong shape             -> RuntimeError        */
+};
+
+enum { CV_ARCH_VIT = 0, CV_ARCH_SAM = 1 };
+enum { CV_DTYPE_F16 = 0, CV_DTYPE_F32 = 1 };   /* storage type of activations/weights; MFMA accumulates fp32 */
+
+typedef struct cv_handle cv_handle;
+
+/* Model hyper-parameters.  Replaces the constructor arguments of
+ *   CellViT(...)      models/segmentation/cell_segmentation/cellvit.py:57-75
+ *   CellViT256(...)   cellvit.py:444-479      CellViTSAM(...)  cellvit.py:514-572, 646-665          */
+typedef struct cv_config {
+    int32_t arch;                 /* CV_ARCH_VIT | CV_ARCH_SAM */
+    int32_t embed_dim, depth, num_heads, mlp_ratio;
+    int32_t extract_layers[4];    /* 1-based block indices of the skip connections */
+    int32_t num_nuclei_classes, num_tissue_classes;
+    int32_t regression_loss;      /* 1: binary branch has 2 extra channels (cellvit.py:133-141) */
+    int32_t patch_size;           /* 16 */
+    int32_t window_size;          /* SAM: 14 */
+    int32_t n_global;             /* SAM: number of global-attention blocks */
+    int32_t global_attn_indexes[8];
+    int32_t neck_chans;           /* SAM: 256 */
+    int32_t compute_dtype;        /* CV_DTYPE_F16 (production) | CV_DTYPE_F32 (parity/debug) */
+} cv_config;
+
+/* Device buffers for the outputs of one forward call (fp32, contiguous, caller-allocated; NULL = skip).
+ * Shapes follow the dict returned by CellViT.forward (cellvit.py:160-169).                            */
+typedef struct cv_outputs {
+    float* tissue_types;          /* [B, num_tissue_classes]                       */
+    float* nuclei_binary_map;     /* [B, 2, H, W]                                  */
+    float* hv_map;                /* [B, 2, H, W]                                  */
+    float* nuclei_type_map;       /* [B, num_nuclei_classes, H, W]                 */
+    float* regression_map;        /* [B, 2, H, W] if regression_loss               */
+    float* tokens_nhwc;           /* [B, H/16, W/16, D]; the shim returns .permute(0,3,1,2) == z4 */
+    uint8_t* binary_argmax;       /* [B, H, W] argmax over nuclei_binary_map channels (cellvit.py:372) */
+    uint8_t* type_argmax;         /* [B, H, W] argmax over nuclei_type_map channels   (cellvit.py:369) */
+} cv_outputs;
+
+const char* cv_last_error(void);
+
+/* nn.Module construction — cellvit.py:57-151 / 514-572. */
+int cv_create(const cv_config* cfg, cv_handle** out);
+int cv_destroy(cv_handle* h);
+
+/* model.load_state_dict(ckpt["model_state_dict"]) — cell_detection.py:137, key names as produced by
+ * the reference modules (base_trainer.py:229-245).  host_ptr: contiguous fp32 (dtype 1) or int64
+ * (dtype 2, only num_batches_tracked) host data.  Unknown keys are rejected.                          */
+int cv_load_weight(cv_handle* h, const char* ref_key, const void* host_ptr, int dtype,
+                   const int64_t* shape, int ndim);
+
+/* model.eval().to(device) — cell_detection.py:138-140: fold BatchNorm+bias into the conv weights,
+ * repack ConvTranspose2d as 4 pointwise GEMMs, cast to the compute dtype, upload.                     */
+int cv_finalize(cv_handle* h);
+
+/* Fix the input geometry (allocates the workspace).  The reference derives these per call from
+ * x.shape; a fixed geometry lets all launches be enqueued without host round trips.                   */
+int cv_set_geometry(cv_handle* h, int max_batch, int H, int W);
+
+/* Input-size dependent tables, fp32 host data, computed by the caller with the reference's own
+ * formulas (the shim uses the identical torch ops):
+ *   "pos_table"      [ntok, D]   ViT: interpolate_pos_encoding (vits_histo.py:377-402), cls row first
+ *                                 SAM: pos_embed[:, :gh, :gw, :] (cell_segmentation/utils.py:222-224)
+ *   "rel_h.<i>"      [2*KH-1, hd]  get_rel_pos resize of block i (SAM/image_encoder.py:333-344)
+ *   "rel_w.<i>"      [2*KW-1, hd]                                                                     */
+int cv_set_derived(cv_handle* h, const char* name, const float* host_ptr, const int64_t* shape, int ndim);
+
+/* CellViT.forward(x, retrieve_tokens) — cellvit.py:153-210 (ViT), :586-644 (SAM).
+ * x_dev: fp32 NCHW [B,3,H,W] normalised tile batch on the device.                                     */
+int cv_forward(cv_handle* h, const float* x_dev, int B, int H, int W, const cv_outputs* out, void* stream);
+
+/* Debug taps (synchronises): copy a named intermediate of the LAST forward to host memory as fp32.
+ * names: "tokens0", "block<i>", "z<1..4>", "skip<0..3>".  Returns the element count in *n_out.        */
+int cv_set_debug(cv_handle* h, int enable);
+int cv_debug_read(cv_handle* h, const char* name, float* host_dst, size_t capacity, size_t* n_out);
+
+/* ---- single-operator entry points (the -m gpu parity tests drive the kernels through these) ---- */
+/* out[M,N] = act(A[M,K] · W[N,K]^T + bias) (+ residual); A, W device buffers of `dtype`.              */
+int cv_op_linear(int dtype, const void* A, const void* W, const float* bias, const float* residual,
+                 void* out, int out_f32, int M, int N, int K, int act, void* stream);
+int cv_op_layernorm(int dtype, const float* x, const float* gamma, const float* beta, void* out,
+                    int out_f32, int M, int C, float eps, void* stream);
+/* NHWC 3x3 conv (pad 1) over the channel concat of src1 (C1) and src2 (C2, may be NULL/0);
+ * Wk: [Cout, 9*(C1+C2)] of `dtype`, k = tap*(C1+C2) + c; bias fp32 [Cout] or NULL.                     */
+int cv_op_conv3x3(int dtype, const void* src1, int C1, const void* src2, int C2, const void* Wk,
+                  const float* bias, void* out, int out_f32, int B, int H, int W, int Cout, int relu,
+                  void* stream);
+/* NHWC ConvTranspose2d k2 s2: Wk [4*Cout, Cin] (n = (dy*2+dx)*Cout + co), bias4 fp32 [4*Cout].         */
+int cv_op_convT2x2(int dtype, const void* src, const void* Wk, const float* bias4, void* out,
+                   int B, int H, int W, int Cin, int Cout, void* stream);
+/* One attention layer on token rows x[B*ntok, D] (already normalised): qkv GEMM + scatter, optional
+ * window partition (win > 0, zero-padded tokens) and decomposed rel-pos (tab_h/tab_w != NULL).
+ * out: `dtype` [B*ntok, D] = softmax(...)·v re-assembled in token order (before the output proj).     */
+int cv_op_attention(int dtype, const void* x, const void* Wqkv, const float* bqkv, const float* tab_h,
+                    const float* tab_w, void* out, int B, int gh, int gw, int has_cls, int heads,
+                    int D, int win, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CELLVIT_AMD_H */

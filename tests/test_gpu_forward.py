@@ -1,0 +1,119 @@
+"""GPU: CellViT.forward of the HIP engine against (a) the golden outputs of the imported reference
+and (b) stage-by-stage taps of the CPU oracle.  fp32 storage path: <= 1e-3 abs on logits (the
+tolerance BASELINE.json's north_star states); fp16 path: error statistics + argmax agreement."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, compare_outputs, load_case
+
+pytestmark = pytest.mark.gpu
+
+ATOL_F32 = 1e-3          # north_star: "HV/type logits within 1e-3 fp32"
+ATOL_F16 = 6e-2          # fp16 operands through up to 32 blocks + 4 decoder stages (reported)
+
+
+def _model(cfg, sd, dtype):
+    from cellvit_amd.model import CellViT256, CellViTSAM
+    from cellvit_amd.spec import ARCH_VIT
+    if cfg.arch == ARCH_VIT:
+        m = CellViT256(None, cfg.num_nuclei_classes, cfg.num_tissue_classes, compute_dtype=dtype)
+    else:
+        name = {768: "SAM-B", 1024: "SAM-L", 1280: "SAM-H"}[cfg.embed_dim]
+        m = CellViTSAM(None, cfg.num_nuclei_classes, cfg.num_tissue_classes, name, compute_dtype=dtype)
+    m.load_state_dict(sd)
+    return m
+
+
+def _stage_report(m, cfg, sd, x, B):
+    """Compare debug taps with the CPU oracle, return list of (name, max_abs_err, ref_absmax)."""
+    from oracle import forward_ref
+    taps = {}
+    forward_ref.forward(x, sd, cfg, retrieve_tokens=True, taps=taps)
+    D = cfg.embed_dim
+    H, W = x.shape[-2:]
+    P = (H // 16) * (W // 16)
+    ntok = P + (1 if cfg.arch == 0 else 0)
+    rep = []
+
+    def cmp(name, got, ref):
+        ref = ref.reshape(-1).numpy()
+        rep.append((name, float(np.abs(got - ref).max()), float(np.abs(ref).max())))
+
+    n = B * ntok * D
+    cmp("tokens0", m.debug_tap("tokens0", n), taps["tokens0"])
+    for i in range(cfg.depth):
+        cmp(f"block{i}", m.debug_tap(f"block{i}", n), taps[f"block{i}"])
+    for j, (c, s) in enumerate([(64, 1), (128, 4), (256, 16), (cfg.skip_dims[2], 64)]):
+        got = m.debug_tap(f"skip{j}", B * H * W // s * c)
+        ref = taps[f"skip{j}"].permute(0, 2, 3, 1).contiguous()   # oracle is NCHW, engine is NHWC
+        cmp(f"skip{j}", got, ref)
+    return rep
+
+
+@pytest.mark.parametrize("name", ["vit256_256", "vit256_b2_128x192", "samb_128", "samh_256"])
+def test_forward_fp32_matches_reference_golden(name):
+    cfg, sd, x, gold = load_case(name)
+    m = _model(cfg, sd, "fp32")
+    m.debug_taps = True
+    out = m(x.cuda(), retrieve_tokens=True)
+    torch.cuda.synchronize()
+    rep = _stage_report(m, cfg, sd, x, x.shape[0])
+    print(f"\n[{name} fp32] stage errors (max abs err / ref abs max):")
+    for r in rep:
+        print(f"   {r[0]:10s} {r[1]:.3e} / {r[2]:.3e}")
+    errs = compare_outputs(out, gold, atol=ATOL_F32)
+    print(f"[{name} fp32] output max abs err: {errs}")
+
+
+@pytest.mark.parametrize("name", ["vit256_256", "samb_128", "samh_256"])
+def test_forward_fp16_error_statistics(name):
+    cfg, sd, x, gold = load_case(name)
+    m = _model(cfg, sd, "fp16")
+    out = m(x.cuda(), retrieve_tokens=True)
+    torch.cuda.synchronize()
+    stats = {}
+    for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map", "tissue_types"):
+        a = out[k].float().cpu().numpy()
+        g = gold[k]
+        stats[k] = (float(np.abs(a - g).max()), float(np.abs(a - g).mean()))
+        if a.ndim == 4 and k != "hv_map":
+            stats[k + "_argmax_agree"] = float((a.argmax(1) == g.argmax(1)).mean())
+    print(f"\n[{name} fp16] (max abs, mean abs) / argmax agreement: {stats}")
+    for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
+        assert stats[k][0] < ATOL_F16, (k, stats[k])
+    assert stats["nuclei_binary_map_argmax_agree"] > 0.99
+    assert stats["nuclei_type_map_argmax_agree"] > 0.98
+
+
+def test_forward_fp32_samh_1024_crops():
+    """BASELINE.json configs[2] shape: SAM-H, one 1024x1024 tile, against reference crops/statistics."""
+    cfg, sd, x, gold = load_case("samh_1024")
+    m = _model(cfg, sd, "fp32")
+    out = m(x.cuda(), retrieve_tokens=True)
+    torch.cuda.synchronize()
+    errs = compare_outputs(out, gold, atol=ATOL_F32)
+    print(f"\n[samh_1024 fp32] crop max abs err: {errs}")
+    for k in ("nuclei_binary_map", "nuclei_type_map"):
+        hist = np.bincount(out[k].argmax(1).cpu().numpy().ravel(), minlength=out[k].shape[1])
+        diff = np.abs(hist - gold[k + "_argmax_hist"]).sum()
+        assert diff <= 1e-4 * hist.sum(), (k, hist, gold[k + "_argmax_hist"])
+
+
+def test_forward_errors():
+    cfg, sd, x, _ = load_case("vit256_256")
+    m = _model(cfg, sd, "fp32")
+    with pytest.raises(AssertionError):
+        m(x[..., :250].cuda())
+    with pytest.raises(RuntimeError):
+        m(x)   # CPU tensor: no fallback
+
+
+def test_autocast_selects_fp16_engine():
+    cfg, sd, x, gold = load_case("vit256_256")
+    m = _model(cfg, sd, "auto")
+    with torch.autocast(device_type="cuda", dtype=torch.float16):
+        out = m(x.cuda())
+    from cellvit_amd import _lib
+    assert list(m._engines.keys()) == [_lib.DTYPE_F16]
+    assert np.abs(out["hv_map"].cpu().numpy() - gold["hv_map"]).max() < ATOL_F16
