@@ -69,7 +69,8 @@ def test_layernorm_rows(dtype, M, Cc):
     w = torch.rand(Cc, generator=g) + 0.5
     b = torch.randn(Cc, generator=g) * 0.1
     out = torch.empty(M, Cc, device="cuda", dtype=torch.float16 if dtype == F16 else torch.float32)
-    L.check(lib.cv_op_layernorm(dtype, _p(x.cuda()), _p(w.cuda()), _p(b.cuda()), _p(out), 0, M, Cc, 1e-6, None))
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()   # keep the device tensors alive across the call
+    L.check(lib.cv_op_layernorm(dtype, _p(xd), _p(wd), _p(bd), _p(out), 0, M, Cc, 1e-6, None))
     torch.cuda.synchronize()
     ref = F.layer_norm(x, (Cc,), w, b, 1e-6)
     assert _rel_err(out.float().cpu(), ref) < (1e-5 if dtype == F32 else 1e-3)
@@ -96,7 +97,8 @@ def test_conv3x3(dtype, B, H, W_, C1, C2, Cout, relu):
     x2d = _dev(x2, dtype) if C2 else None
     Wd = _dev(_pack_conv(Wt), dtype)
     out = torch.empty(B, H, W_, Cout, device="cuda", dtype=torch.float32)
-    L.check(lib.cv_op_conv3x3(dtype, _p(x1d), C1, _p(x2d), C2, _p(Wd), _p(bias.cuda()), _p(out), 1, B, H, W_, Cout,
+    biasd = bias.cuda()
+    L.check(lib.cv_op_conv3x3(dtype, _p(x1d), C1, _p(x2d), C2, _p(Wd), _p(biasd), _p(out), 1, B, H, W_, Cout,
                               relu, None))
     torch.cuda.synchronize()
     xin = x1d.float().cpu() if not C2 else torch.cat([x1d.float().cpu(), x2d.float().cpu()], dim=-1)
@@ -191,8 +193,10 @@ def test_attention(dtype, B, gh, gw, has_cls, heads, D, win, rel):
     tab_w = torch.randn(2 * KW - 1, hd, generator=g) * 0.2 if rel else None
     xd, Wd = _dev(x, dtype), _dev(Wqkv, dtype)
     out = torch.zeros(B * ntok, D, device="cuda", dtype=torch.float16 if dtype == F16 else torch.float32)
-    L.check(lib.cv_op_attention(dtype, _p(xd), _p(Wd), _p(bqkv.cuda()), _p(tab_h.cuda() if rel else None),
-                                _p(tab_w.cuda() if rel else None), _p(out), B, gh, gw, has_cls, heads, D, win, None))
+    bd = bqkv.cuda()
+    thd, twd = (tab_h.cuda(), tab_w.cuda()) if rel else (None, None)
+    L.check(lib.cv_op_attention(dtype, _p(xd), _p(Wd), _p(bd), _p(thd), _p(twd), _p(out), B, gh, gw, has_cls, heads,
+                                D, win, None))
     torch.cuda.synchronize()
     ref = _attention_ref(xd.float().cpu(), Wd.float().cpu(), bqkv, tab_h, tab_w, B, gh, gw, has_cls, heads, D, win)
     err = _rel_err(out.float().cpu(), ref)
