@@ -58,6 +58,23 @@ SYMBOLS = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
+SYMBOLS.update({
+    "cv_pp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "cv_pp_destroy": (C.c_int, [C.c_void_p]),
+    "cv_pp_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cv_pp_run_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cv_pp_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+})
+
+
+class cv_instance(C.Structure):
+    _fields_ = [("id", C.c_int32), ("rmin", C.c_int32), ("cmin", C.c_int32), ("rmax", C.c_int32), ("cmax", C.c_int32),
+                ("npix", C.c_int32), ("type", C.c_int32), ("contour_off", C.c_int32), ("contour_len", C.c_int32),
+                ("reserved", C.c_int32), ("cx", C.c_double), ("cy", C.c_double), ("type_prob", C.c_double)]
+
+
 _lib = None
 
 

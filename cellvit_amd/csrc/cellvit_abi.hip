@@ -14,6 +14,7 @@
 #include "attention.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "postproc.h"
 
 static thread_local char g_err[1024] = "";
 void cva_set_error(const char* fmt, ...) {
@@ -847,4 +848,73 @@ extern "C" int cv_op_attention(int dtype, const void* x, const void* Wqkv, const
     if (hipStreamSynchronize(st) != hipSuccess && !rc) { cva_set_error("attention: stream sync failed: %s", hipGetErrorString(hipGetLastError())); rc = CV_ERR_HIP; }
     free_pool(pool);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// post-processing handle
+// ------------------------------------------------------------------------------------------------
+struct cv_pp {
+    PostprocWorkspace* ws = nullptr;
+    PostprocDims d{};
+    int last_B = 0;
+};
+
+static_assert(sizeof(cv_instance) == sizeof(InstanceRec), "cv_instance / InstanceRec layout drift");
+
+extern "C" int cv_pp_create(int max_batch, int H, int W, int max_inst, int max_pts, cv_pp** out) {
+    if (!out || max_batch <= 0 || H <= 0 || W <= 0 || max_inst <= 0 || max_pts < 0) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { cva_set_error("no HIP device visible (no CPU fallback)"); return CV_ERR_HIP; }
+    cv_pp* p = new cv_pp();
+    p->d.B = max_batch; p->d.H = H; p->d.W = W; p->d.max_inst = max_inst; p->d.max_pts = max_pts;
+    p->d.max_ids = std::max(64, H * W / 8);
+    if (pp_workspace_create(p->d, &p->ws) != 0) { delete p; cva_set_error("postproc workspace allocation failed"); return CV_ERR_HIP; }
+    *out = p;
+    return CV_OK;
+}
+
+extern "C" int cv_pp_destroy(cv_pp* p) {
+    if (!p) return CV_OK;
+    pp_workspace_destroy(p->ws);
+    delete p;
+    return CV_OK;
+}
+
+extern "C" int cv_pp_run_params(cv_pp* p, const uint8_t* bin, const uint8_t* type, const float* hv, int B,
+                                int object_size, int ksize, int nr_types, int32_t* inst_map, cv_instance* recs,
+                                int32_t* n_recs, int32_t* contours, int32_t* n_pts, void* stream) {
+    if (!p || !bin || !hv || !inst_map || !recs || !n_recs || !n_pts) { cva_set_error("null argument"); return CV_ERR_INVALID; }
+    if (ksize != 21 && ksize != 11) { cva_set_error("Sobel ksize must be 21 or 11"); return CV_ERR_INVALID; }
+    if (nr_types < 0 || nr_types > 8 || (nr_types > 0 && !type)) { cva_set_error("nr_types must be in [0, 8]"); return CV_ERR_INVALID; }
+    if (B <= 0 || B > p->d.B) { cva_set_error("batch %d exceeds the handle's max_batch %d", B, p->d.B); return CV_ERR_INVALID; }
+    const int rc = pp_run(p->ws, bin, type, hv, B, object_size, ksize, nr_types, inst_map, reinterpret_cast<InstanceRec*>(recs),
+                          n_recs, contours, n_pts, reinterpret_cast<hipStream_t>(stream));
+    if (rc) { cva_set_error("postproc launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError())); return CV_ERR_HIP; }
+    p->last_B = B;
+    return CV_OK;
+}
+
+extern "C" int cv_pp_run(cv_pp* p, const uint8_t* bin, const uint8_t* type, const float* hv, int B, int magnification,
+                         int nr_types, int32_t* inst_map, cv_instance* recs, int32_t* n_recs, int32_t* contours,
+                         int32_t* n_pts, void* stream) {
+    int object_size, ksize;
+    if (magnification == 40) { object_size = 10; ksize = 21; }       // post_proc_cellvit.py:55-60
+    else if (magnification == 20) { object_size = 3; ksize = 11; }
+    else { cva_set_error("Unknown magnification"); return CV_ERR_UNSUPPORTED; }
+    return cv_pp_run_params(p, bin, type, hv, B, object_size, ksize, nr_types, inst_map, recs, n_recs, contours, n_pts, stream);
+}
+
+extern "C" int cv_pp_debug_read(cv_pp* p, const char* name, void* host_dst, size_t bytes) {
+    if (!p || !name || !host_dst || p->last_B <= 0) { cva_set_error("nothing to read"); return CV_ERR_STATE; }
+    const size_t n = (size_t)p->last_B * p->d.H * p->d.W;
+    const void* src; size_t need;
+    const std::string s(name);
+    if (s == "dist") { src = pp_dbg_dist(p->ws); need = n * 8; }
+    else if (s == "marker") { src = pp_dbg_marker(p->ws); need = n * 4; }
+    else if (s == "blb") { src = pp_dbg_blb_u8(p->ws); need = n; }
+    else { cva_set_error("unknown tap '%s'", name); return CV_ERR_INVALID; }
+    if (bytes < need) { cva_set_error("need %zu bytes", need); return CV_ERR_INVALID; }
+    CVA_CHECK_HIP(hipDeviceSynchronize());
+    CVA_CHECK_HIP(hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+    return CV_OK;
 }

@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference post-processing interface, backed by the on-device HIP chain.
+
+Reference surface reproduced (same names / argument meaning / error behaviour):
+  * ``DetectionCellPostProcessor(nr_types, magnification, gt).post_process_cell_segmentation(pred_map)``
+      — cell_segmentation/utils/post_proc_cellvit.py:33-153
+  * ``calculate_instance_map(predictions, magnification)`` glue of CellViT — cellvit.py:332-383
+The numerical work (CC labelling, Sobel, marker watershed, per-instance records, contours) runs in
+libcellvit_amd.so on the GPU; this module only moves pointers and unpacks the record arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Literal, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class _PPEngine:
+    _cache: Dict[tuple, "_PPEngine"] = {}
+
+    def __init__(self, device: torch.device, B: int, H: int, W: int):
+        self.lib = _lib.load()
+        self.B, self.H, self.W = B, H, W
+        self.max_inst = max(256, H * W // 128)       # record slots per tile (1024^2 -> 8192)
+        self.max_pts = max(4096, H * W // 8)         # contour points per tile
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self.lib.cv_pp_create(B, H, W, self.max_inst, self.max_pts, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    @classmethod
+    def get(cls, device: torch.device, B: int, H: int, W: int) -> "_PPEngine":
+        key = (device.index if device.index is not None else torch.cuda.current_device(), H, W)
+        e = cls._cache.get(key)
+        if e is None or e.B < B:
+            if e is not None:
+                e.close()
+            e = cls(device, B, H, W)
+            cls._cache[key] = e
+        return e
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cv_pp_destroy(self.h)
+            self.h = None
+
+
+def postprocess_device(bin_argmax: torch.Tensor, type_argmax: Optional[torch.Tensor], hv: torch.Tensor,
+                       nr_types: int, object_size: int, ksize: int, want_contours: bool = True):
+    """Run the chain for a batch that is already on the GPU.  Returns device tensors
+    (inst_map i32 [B,H,W], recs u8 [B,max_inst,sizeof(cv_instance)], n_recs i32 [B],
+    contours i32 [B,max_pts,2] | None, n_pts i32 [B]) — nothing is copied to the host."""
+    if not bin_argmax.is_cuda:
+        raise RuntimeError("cellvit_amd post-processing runs on the MI355X only (no CPU fallback)")
+    dev = bin_argmax.device
+    B, H, W = bin_argmax.shape
+    e = _PPEngine.get(dev, B, H, W)
+    bin_argmax = bin_argmax.contiguous()
+    hv = hv.contiguous().float()
+    if type_argmax is not None:
+        type_argmax = type_argmax.contiguous()
+    with torch.cuda.device(dev):
+        inst = torch.empty((B, H, W), device=dev, dtype=torch.int32)
+        recs = torch.empty((B, e.max_inst, C.sizeof(_lib.cv_instance)), device=dev, dtype=torch.uint8)
+        n_recs = torch.zeros((B,), device=dev, dtype=torch.int32)
+        n_pts = torch.zeros((B,), device=dev, dtype=torch.int32)
+        contours = torch.empty((B, e.max_pts, 2), device=dev, dtype=torch.int32) if want_contours else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(e.lib.cv_pp_run_params(
+            e.h, bin_argmax.data_ptr(), type_argmax.data_ptr() if type_argmax is not None else None, hv.data_ptr(), B,
+            int(object_size), int(ksize), int(nr_types if type_argmax is not None else 0), inst.data_ptr(),
+            recs.data_ptr(), n_recs.data_ptr(), contours.data_ptr() if contours is not None else None,
+            n_pts.data_ptr(), C.c_void_p(stream)))
+    return inst, recs, n_recs, contours, n_pts
+
+
+def records_to_dicts(recs: torch.Tensor, n_recs: torch.Tensor, contours: Optional[torch.Tensor],
+                     n_pts: torch.Tensor) -> List[dict]:
+    """Device record arrays -> the reference's per-tile dicts (post_proc:126-151).  This is the point
+    where cell records leave the device (the writer / geojson step)."""
+    nr = n_recs.cpu().numpy()
+    npt = n_pts.cpu().numpy()
+    out = []
+    for b in range(recs.shape[0]):
+        n = int(nr[b])
+        raw = recs[b, :n].cpu().numpy().tobytes()
+        arr = (_lib.cv_instance * n).from_buffer_copy(raw) if n else []
+        pts = contours[b, : int(npt[b])].cpu().numpy() if contours is not None else None
+        d = {}
+        for r in arr:
+            if pts is not None and r.contour_len < 3:      # "< 3 points dont make a contour" (post_proc:113-116)
+                continue
+            d[int(r.id)] = {
+                "bbox": np.array([[r.rmin, r.cmin], [r.rmax, r.cmax]]),
+                "centroid": np.array([r.cx, r.cy]),
+                "contour": pts[r.contour_off:r.contour_off + r.contour_len].copy() if pts is not None else None,
+                "type_prob": float(r.type_prob),
+                "type": int(r.type),
+            }
+        out.append(d)
+    return out
+
+
+def _params(magnification: int, gt: bool = False) -> Tuple[int, int]:
+    if magnification == 40:
+        object_size, k_size = 10, 21
+    elif magnification == 20:
+        object_size, k_size = 3, 11
+    else:
+        raise NotImplementedError("Unknown magnification")
+    if gt:
+        object_size, k_size = 100, 21
+    return object_size, k_size
+
+
+class DetectionCellPostProcessor:
+    """post_proc_cellvit.py:33-65 — same constructor, same ``post_process_cell_segmentation``."""
+
+    def __init__(self, nr_types: int = None, magnification: Literal[20, 40] = 40, gt: bool = False) -> None:
+        self.nr_types = nr_types
+        self.magnification = magnification
+        self.gt = gt
+        self.object_size, self.k_size = _params(magnification, gt)
+
+    def post_process_cell_segmentation(self, pred_map: np.ndarray, device: Optional[torch.device] = None
+                                       ) -> Tuple[np.ndarray, dict]:
+        """pred_map [H, W, 4] = (type, binary, hv0, hv1) (or [H, W, 3] without types) -> (instance map, dict)."""
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        pm = torch.as_tensor(np.ascontiguousarray(pred_map))
+        if self.nr_types is not None:
+            typ = pm[..., 0].to(torch.int32).to(torch.uint8)[None].to(device)
+            inst_ch = pm[..., 1:]
+        else:
+            typ, inst_ch = None, pm
+        binm = (inst_ch[..., 0].float() >= 0.5).to(torch.uint8)[None].to(device)
+        hv = inst_ch[..., 1:3].float().permute(2, 0, 1)[None].to(device)
+        inst, recs, n_recs, contours, n_pts = postprocess_device(binm, typ, hv, self.nr_types or 0, self.object_size,
+                                                                 self.k_size)
+        d = records_to_dicts(recs, n_recs, contours, n_pts)[0]
+        return inst[0].cpu().numpy(), d
+
+
+def calculate_instance_map(predictions: dict, num_nuclei_classes: int, magnification: Literal[20, 40] = 40
+                           ) -> Tuple[torch.Tensor, List[dict]]:
+    """cellvit.py:332-383: predictions (BCHW, softmax or raw logits — only the argmax is consumed) ->
+    (instance maps [B,H,W] float32 on the host like the reference, list of per-image nucleus dicts)."""
+    object_size, k_size = _params(magnification)
+    binm = torch.argmax(predictions["nuclei_binary_map"], dim=1).to(torch.uint8)
+    typ = torch.argmax(predictions["nuclei_type_map"], dim=1).to(torch.uint8)
+    hv = predictions["hv_map"]
+    inst, recs, n_recs, contours, n_pts = postprocess_device(binm, typ, hv, num_nuclei_classes, object_size, k_size)
+    return inst.float().cpu(), records_to_dicts(recs, n_recs, contours, n_pts)

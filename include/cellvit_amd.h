@@ -128,6 +128,40 @@ int cv_op_attention(int dtype, const void* x, const void* Wqkv, const float* bqk
                     const float* tab_w, void* out, int B, int gh, int gw, int has_cls, int heads,
                     int D, int win, void* stream);
 
+/* ---- per-tile instance post-processing ------------------------------------------------------------
+ * Replaces DetectionCellPostProcessor.post_process_cell_segmentation + __proc_np_hv
+ *   (cell_segmentation/utils/post_proc_cellvit.py:67-153, 155-249) and the per-sample glue of
+ *   CellViT.calculate_instance_map (cellvit.py:351-383), batched and fully on the device.            */
+typedef struct cv_instance {
+    int32_t id;                        /* instance id == surviving marker id (ids are not compacted)  */
+    int32_t rmin, cmin, rmax, cmax;    /* bbox [[rmin,cmin],[rmax,cmax]], max exclusive (tools.py:24-34) */
+    int32_t npix;
+    int32_t type;                      /* majority nucleus type, background replaced by the runner-up  */
+    int32_t contour_off, contour_len;  /* into the tile's (x, y) int32 contour array; len < 3 => the
+                                          reference drops the instance from its dict (post_proc:113-116) */
+    int32_t reserved;
+    double cx, cy;                     /* centroid (x, y), tile coordinates                             */
+    double type_prob;                  /* votes(type) / (npix + 1e-6)  (post_proc:149)                   */
+} cv_instance;
+
+typedef struct cv_pp cv_pp;
+/* max_inst record slots and max_pts contour points per tile; nr_types <= 8. */
+int cv_pp_create(int max_batch, int H, int W, int max_inst, int max_pts, cv_pp** out);
+int cv_pp_destroy(cv_pp* pp);
+/* Device inputs: bin_argmax / type_argmax u8 [B,H,W] (cellvit.py:369-374), hv f32 [B,2,H,W].
+ * Device outputs: inst_map i32 [B,H,W]; recs [B,max_inst]; n_recs, n_pts i32 [B];
+ * contours i32 [B,max_pts,2] (may be NULL).  magnification 40 | 20 else CV_ERR_UNSUPPORTED.            */
+int cv_pp_run(cv_pp* pp, const uint8_t* bin_argmax, const uint8_t* type_argmax, const float* hv, int B,
+              int magnification, int nr_types, int32_t* inst_map, cv_instance* recs, int32_t* n_recs,
+              int32_t* contours, int32_t* n_pts, void* stream);
+/* Same with explicit (object_size, Sobel ksize in {21, 11}) — DetectionCellPostProcessor(gt=True)
+ * uses (100, 21) (post_proc_cellvit.py:63-65).                                                         */
+int cv_pp_run_params(cv_pp* pp, const uint8_t* bin_argmax, const uint8_t* type_argmax, const float* hv, int B,
+                     int object_size, int ksize, int nr_types, int32_t* inst_map, cv_instance* recs,
+                     int32_t* n_recs, int32_t* contours, int32_t* n_pts, void* stream);
+/* Debug taps of the last run (synchronises): "dist" f64 [B,H,W], "marker" i32 [B,H,W], "blb" u8 [B,H,W]. */
+int cv_pp_debug_read(cv_pp* pp, const char* name, void* host_dst, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif
