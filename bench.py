@@ -1,16 +1,26 @@
 #!/usr/bin/env python3
-"""Benchmark of the CellViT inference hot path on MI355X (contract: see the task statement).
+"""Benchmark of the CellViT inference hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--model samh|vit256]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
 
-One *step* = one batch of B synthetic 1024x1024 tiles through forward (ViT encoder + 3-branch
-decoder) + on-device post-processing.  Inputs are resident in HBM before the timed region.
-Metric: whole-job 1024x1024 tiles/s (BASELINE.json).  For N > 1 launch with torch.distributed.run;
-tiles shard across ranks with no data-path collective (weak scaling, B tiles per rank per step).
+One *step* = one batch of B synthetic 1024x1024 tiles through the whole hot path:
+  forward (ViT encoder + shared skips + 3 decoder branches, HIP)  ->  on-device Sobel / marker
+  watershed post-processing up to the per-tile instance records (HIP).
+Inputs (normalised fp32 tiles; synthetic nucleus maps for the post-processing leg) are resident in
+HBM before the timed region.  `value` = whole-job 1024x1024 tiles/s (BASELINE.json metric).
+Tiles shard across ranks with no data-path collective (weak scaling: B tiles per rank per step).
+
+Post-processing input: random-weight logits are salt-and-pepper and contain no nuclei, so — as
+SURVEY §8d prescribes — the post-processing leg of every step runs on seeded synthetic nucleus maps
+(K = 800 ellipses per tile, HV maps as the training targets define them) of the same shape as the
+forward outputs; both legs execute completely on every step.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -18,6 +28,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+METRIC = "1024x1024 tiles/sec end-to-end (fwd+postproc), CellViT-SAM-H"
+MFMA_F16_PEAK_TFLOPS = 2500.0       # dense, /opt/skills/guides/MI355X_MICROARCH.md
+KCLASS = ["gemm_linear(proj/fc1/fc2/patch/neck)", "gemm_qkv", "conv3x3_implicit_gemm", "convT2x2_gemm", "attention"]
 
 
 def parse():
@@ -28,9 +42,35 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="tiles per step per GPU (reference default batch_size 8)")
     ap.add_argument("--model", default="samh", choices=["samh", "vit256"])
     ap.add_argument("--tile", type=int, default=1024)
+    ap.add_argument("--cells", type=int, default=800, help="synthetic nuclei per 1024^2 tile (post-proc input)")
     ap.add_argument("--no-postproc", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
     return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, tile, cells, n_threads=None):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores, one tile."""
+    import numpy as np
+    import torch
+    from cellvit_amd.synth import synth_nuclei_maps
+    from cellvit_amd.weights import normalize_tile, synthetic_tile_u8
+    from oracle import forward_ref, postproc_ref
+    if n_threads:
+        torch.set_num_threads(n_threads)
+    x = torch.from_numpy(normalize_tile(synthetic_tile_u8(0, size=tile, he_like=True)))[None]
+    t0 = time.perf_counter()
+    forward_ref.forward(x, sd, cfg, retrieve_tokens=True)
+    t_fwd = time.perf_counter() - t0
+    tm, bm, hv, _ = synth_nuclei_maps(0, tile, cells)
+    pm = np.stack([tm.astype(np.float32), bm.astype(np.float32), hv[0], hv[1]], -1)
+    t0 = time.perf_counter()
+    postproc_ref.postprocess_tile(pm, 6, 40)
+    t_pp = time.perf_counter() - t0
+    return {"value": 1.0 / (t_fwd + t_pp), "unit": "tiles/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"1 tile {tile}x{tile}: oracle forward (torch fp32, {torch.get_num_threads()} threads) "
+                      f"{t_fwd:.2f} s + oracle post-proc (C, 1 thread) {t_pp:.3f} s",
+            "forward_s": t_fwd, "postproc_s": t_pp}
 
 
 def main():
@@ -44,42 +84,69 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    from cellvit_amd import _lib
     from cellvit_amd.model import CellViT256, CellViTSAM
+    from cellvit_amd.postproc import postprocess_device
     from cellvit_amd.spec import cellvit256_config, cellvit_sam_config
+    from cellvit_amd.synth import synth_nuclei_maps
     from cellvit_amd.weights import make_state_dict, normalize_tile, synthetic_tile_u8
 
     if args.model == "samh":
         cfg = cellvit_sam_config("SAM-H")
         model = CellViTSAM(None, 6, 19, "SAM-H", compute_dtype="fp16")
-        workload = "CellViT-SAM-H fp16, 1024x1024 tiles, fwd + on-GPU Sobel/watershed postproc (BASELINE configs[2])"
+        workload = ("CellViT-SAM-H fp16, 1024x1024 tiles, full on-GPU fwd + Sobel/watershed postproc "
+                    "(BASELINE.json configs[2])")
+        flops_per_tile = 9.50e12 * (args.tile / 1024.0) ** 2      # SURVEY §8d algorithmic FLOPs
     else:
         cfg = cellvit256_config()
         model = CellViT256(None, 6, 19, compute_dtype="fp16")
-        workload = "CellViT-256 fp16, 1024x1024 tiles (BASELINE configs[1])"
-    model.load_state_dict(make_state_dict(cfg, seed=0))
+        workload = "CellViT-256 fp16, 1024x1024 tiles, fwd + on-GPU postproc (BASELINE.json configs[1] + postproc)"
+        flops_per_tile = 3.38e12 * (args.tile / 1024.0) ** 2
+    sd = make_state_dict(cfg, seed=0)
+    model.load_state_dict(sd)
 
     B, T = args.batch, args.tile
-    tiles = [normalize_tile(synthetic_tile_u8(rank * B + i, size=T, he_like=True)) for i in range(B)]
-    x = torch.from_numpy(np.stack(tiles)).to(dev)
+    x = torch.from_numpy(np.stack([normalize_tile(synthetic_tile_u8(rank * B + i, size=T, he_like=True))
+                                   for i in range(B)])).to(dev)
+    do_pp = not args.no_postproc
+    if do_pp:
+        maps = [synth_nuclei_maps(rank * B + i, T, args.cells) for i in range(B)]
+        pp_type = torch.from_numpy(np.stack([m[0] for m in maps])).to(dev)
+        pp_bin = torch.from_numpy(np.stack([m[1] for m in maps])).to(dev)
+        pp_hv = torch.from_numpy(np.stack([m[2] for m in maps])).to(dev)
 
-    def step():
+    ev = {"f0": [], "f1": [], "p1": []}
+
+    def step(record=False):
+        if record:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record(); ev["f0"].append(e0)
         out = model(x, retrieve_tokens=True)
-        return out
+        if record:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record(); ev["f1"].append(e1)
+        res = None
+        if do_pp:
+            res = postprocess_device(pp_bin, pp_type, pp_hv, 6, 10, 21, want_contours=True)
+        if record:
+            e2 = torch.cuda.Event(enable_timing=True); e2.record(); ev["p1"].append(e2)
+        return out, res
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    eng = model._last_engine
+    kernel_events = not args.no_kernel_events
+    if kernel_events:
+        _lib.check(eng.lib.cv_profile_enable(eng.h, 1))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        out, res = step(record=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -89,18 +156,49 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
     if rank == 0:
-        ms = dt / args.steps * 1e3
+        fwd_ms = sum(a.elapsed_time(b) for a, b in zip(ev["f0"], ev["f1"])) / args.steps
+        pp_ms = sum(a.elapsed_time(b) for a, b in zip(ev["f1"], ev["p1"])) / args.steps
+        n_inst = int(res[2].sum().item()) if res is not None else 0
+        roofline = None
+        kstats = {}
+        if kernel_events:
+            ms = (C.c_double * 5)(); n = (C.c_int64 * 5)(); fl = (C.c_double * 5)()
+            _lib.check(eng.lib.cv_profile_collect(eng.h, ms, n, fl))
+            _lib.check(eng.lib.cv_profile_enable(eng.h, 0))
+            for i, name in enumerate(KCLASS):
+                if n[i]:
+                    kstats[name] = {"launches": int(n[i]), "avg_us": 1e3 * ms[i] / n[i], "total_ms_per_step": ms[i] / args.steps,
+                                    "tflops": fl[i] / (ms[i] * 1e-3) / 1e12}
+            dom = max(range(5), key=lambda i: ms[i])
+            ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(KCLASS[dom])
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "mfma", "kernel": KCLASS[dom], "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS,
+                        "flops_per_launch": fl[dom] / n[dom], "avg_launch_us": 1e3 * ms[dom] / n[dom],
+                        "launches": int(n[dom]), "traffic": traffic}
         rec = {
-            "metric": "1024x1024 tiles/sec end-to-end (fwd+postproc), CellViT-SAM-H",
-            "value": world * B * args.steps / dt,
-            "unit": "tiles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
+            "metric": METRIC, "value": world * B * args.steps / dt, "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": workload, "tile": T, "tiles_per_step_per_gpu": B, "global_batch": world * B,
-                       "parallelism": f"tile-sharded x{world}", "postproc": False},
+                       "parallelism": f"tile-sharded x{world}, no data-path collective",
+                       "postproc": bool(do_pp), "postproc_input": f"synthetic nuclei maps, {args.cells} cells/tile",
+                       "instances_per_step": n_inst},
+            "stage_ms_per_step": {"forward": fwd_ms, "postproc": pp_ms},
+            "whole_forward_mfma_frac": (B * flops_per_tile / (fwd_ms * 1e-3)) / (MFMA_F16_PEAK_TFLOPS * 1e12),
+            "roofline": roofline,
+            "kernel_classes": kstats,
         }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(cfg, sd, T, args.cells)
         print(json.dumps(rec))
     if world > 1:
         dist.destroy_process_group()

@@ -59,6 +59,8 @@ SYMBOLS = {
 }
 
 SYMBOLS.update({
+    "cv_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "cv_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "cv_pp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "cv_pp_destroy": (C.c_int, [C.c_void_p]),
     "cv_pp_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -27,6 +27,36 @@ extern "C" const char* cv_last_error(void) { return g_err; }
 
 using namespace cva;
 
+// ------------------------------------------------------------------------------------------------
+// live per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
+// ------------------------------------------------------------------------------------------------
+namespace {
+enum { KC_GEMM_LINEAR = 0, KC_GEMM_QKV = 1, KC_CONV3 = 2, KC_CONVT = 3, KC_ATTN = 4, KC_COUNT = 5 };
+struct Profiler {
+    bool on = false;
+    struct Rec { hipEvent_t a, b; int cls; double flops; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    void begin(int cls, double flops, hipStream_t st) {
+        if (!on) return;
+        Rec r; r.a = get(); r.b = get(); r.cls = cls; r.flops = flops;
+        (void)hipEventRecord(r.a, st);
+        recs.push_back(r);
+    }
+    void end(hipStream_t st) { if (on && !recs.empty()) (void)hipEventRecord(recs.back().b, st); }
+};
+thread_local Profiler* g_prof = nullptr;
+struct ProfScope {
+    hipStream_t st; bool active;
+    ProfScope(int cls, double flops, hipStream_t s) : st(s), active(g_prof && g_prof->on) { if (active) g_prof->begin(cls, flops, st); }
+    ~ProfScope() { if (active) g_prof->end(st); }
+};
+}  // namespace
+
 namespace {
 
 constexpr float LN_EPS = 1e-6f;   // cellvit.py:99, 559; SAM/utils.py:39
@@ -43,7 +73,7 @@ struct HostTensor {
 };
 
 struct LinearW { void* W = nullptr; float* bias = nullptr; int N = 0, K = 0, ldw = 0; };
-struct ConvW { void* W = nullptr; float* bias = nullptr; int Cout = 0, Ctot = 0, K = 0, ldw = 0; int relu = 1; };
+struct ConvW { void* W = nullptr; float* bias = nullptr; int Cout = 0, Ctot = 0, K = 0, ldw = 0; int relu = 1; int Cin_real = 0; };
 struct ConvTW { void* W = nullptr; float* bias4 = nullptr; int Cin = 0, Cout = 0, ldw = 0; };
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct HeadW { float* W = nullptr; float* b = nullptr; int n_out = 0; };
@@ -90,6 +120,7 @@ struct cv_handle {
           *small_f32 = nullptr, *dbg_blocks = nullptr, *dbg_tokens0 = nullptr;
     size_t ws_bytes = 0;
     int last_B = 0;
+    Profiler prof;
 };
 
 namespace {
@@ -198,7 +229,7 @@ int pack_conv3(cv_handle* h, const std::string& conv_key, const std::string& bn_
                 wk[(size_t)co * K + t * Cpad + ci] = (float)((double)w->data[((size_t)co * Cin + ci) * 9 + t] * scale);
         bias[co] = (float)((cb ? (double)cb->data[co] : 0.0) * scale + shift);
     }
-    out->Cout = Cout; out->Ctot = Cpad; out->K = K; out->relu = relu;
+    out->Cout = Cout; out->Ctot = Cpad; out->K = K; out->relu = relu; out->Cin_real = Cin;
     out->ldw = round_up(K, bk_of(h->cfg.compute_dtype));
     CVA_TRY(upload_matrix(h, wk.data(), Cout, K, out->ldw, &out->W));
     if (has_bias || g) CVA_TRY(upload_f32(h, bias.data(), Cout, &out->bias));
@@ -280,6 +311,7 @@ int run_linear(const void* A, int lda, const LinearW& w, const float* res, int l
     p.bias = w.bias; p.act = act; p.res = res; p.ldres = ldres; p.res_mod = res_mod;
     p.out_mode = OUT_LINEAR; p.out_f32 = out_f32; p.out = out; p.ldc = ldc;
     p.o_rpi = o_rpi; p.o_extra = o_extra; p.o_off = o_off;
+    ProfScope ps(KC_GEMM_LINEAR, 2.0 * M * (double)w.N * w.K, st);
     const int rc = launch_gemm<T>(p, A_LINEAR, st);
     if (rc) { cva_set_error("gemm launch failed (%d)", rc); return CV_ERR_HIP; }
     return CV_OK;
@@ -294,6 +326,7 @@ int run_conv3(const void* s1, int C1, const void* s2, int C2, const ConvW& w, vo
     p.H = Hs; p.Wd = Ws; p.C1 = C1; p.C2 = C2;
     p.bias = w.bias; p.act = w.relu ? ACT_RELU : ACT_NONE;
     p.out_mode = OUT_LINEAR; p.out_f32 = out_f32; p.out = out; p.ldc = w.Cout;
+    ProfScope ps(KC_CONV3, 2.0 * p.M * (double)w.Cout * 9.0 * w.Cin_real, st);
     const int rc = launch_gemm<T>(p, A_CONV3, st);
     if (rc) { cva_set_error("conv3x3 launch failed (%d)", rc); return CV_ERR_HIP; }
     return CV_OK;
@@ -305,6 +338,7 @@ int run_convT(const void* src, const ConvTW& w, void* out, int B, int Hs, int Ws
     p.M = B * Hs * Ws; p.N = 4 * w.Cout; p.K = w.Cin; p.A = src; p.W = w.W; p.lda = w.Cin; p.ldw = w.ldw;
     p.H = Hs; p.Wd = Ws;
     p.bias = w.bias4; p.act = ACT_NONE; p.out_mode = OUT_CONVT; p.out_f32 = 0; p.out = out;
+    ProfScope ps(KC_CONVT, 2.0 * p.M * 4.0 * w.Cout * w.Cin, st);
     const int rc = launch_gemm<T>(p, A_LINEAR, st);
     if (rc) { cva_set_error("convT launch failed (%d)", rc); return CV_ERR_HIP; }
     return CV_OK;
@@ -327,7 +361,7 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
     g.q_out = Q; g.k_out = K; g.vt_out = Vt;
     g.D = D; g.hd = hd; g.heads = heads; g.ntok = ntok; g.L = L; g.Lp = Lp;
     g.win = window ? ws : 0; g.gw = gw; g.gh = gh; g.nwx = nwx; g.nwy = nwy;
-    CVA_LAUNCH(launch_gemm<T>(g, A_LINEAR, st));
+    { ProfScope ps(KC_GEMM_QKV, 2.0 * g.M * (double)g.N * g.K, st); CVA_LAUNCH(launch_gemm<T>(g, A_LINEAR, st)); }
     if (window && (nwy * ws != gh || nwx * ws != gw)) {
         PadKVParams pk{};
         pk.K = K; pk.Vt = Vt; pk.qkv_bias = qkv.bias; pk.B = B; pk.heads = heads; pk.hd = hd; pk.D = D; pk.L = L;
@@ -346,7 +380,8 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
     a.S = S; a.heads = heads; a.L = L; a.Lp = Lp; a.hd = hd; a.D = D; a.nk = L; a.KH = KH; a.KW = KW;
     a.scale = 1.0f / std::sqrt((float)hd);
     a.ntok = ntok; a.win = window ? ws : 0; a.gw = gw; a.gh = gh; a.nwx = nwx; a.nwy = nwy;
-    CVA_LAUNCH(launch_attention<T>(a, st));
+    { ProfScope ps(KC_ATTN, 4.0 * (double)B * P * (window ? L : ntok) * hd * heads + (window ? 0.0 : 4.0 * B * has_cls * (double)ntok * hd * heads), st);
+      CVA_LAUNCH(launch_attention<T>(a, st)); }
     return CV_OK;
 }
 
@@ -722,8 +757,11 @@ extern "C" int cv_forward(cv_handle* h, const float* x_dev, int B, int H, int W,
         for (int i = 0; i < h->cfg.depth; ++i)
             if (!h->blocks[i].tab_h || !h->blocks[i].tab_w) { cva_set_error("derived rel-pos tables of block %d not set", i); return CV_ERR_STATE; }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return h->cfg.compute_dtype == CV_DTYPE_F16 ? forward_impl<half_t>(h, x_dev, B, out, st)
-                                                 : forward_impl<float>(h, x_dev, B, out, st);
+    g_prof = &h->prof;
+    const int rc = h->cfg.compute_dtype == CV_DTYPE_F16 ? forward_impl<half_t>(h, x_dev, B, out, st)
+                                                         : forward_impl<float>(h, x_dev, B, out, st);
+    g_prof = nullptr;
+    return rc;
 }
 
 extern "C" int cv_set_debug(cv_handle* h, int enable) {
@@ -805,7 +843,7 @@ extern "C" int cv_op_conv3x3(int dtype, const void* src1, int C1, const void* sr
     const int pe = dtype == CV_DTYPE_F16 ? 8 : 4;
     const int K = 9 * (C1 + C2);
     if (C1 % pe || C2 % pe || K % bk_of(dtype)) { cva_set_error("cv_op_conv3x3: channels %% %d, 9*C %% %d required", pe, bk_of(dtype)); return CV_ERR_INVALID; }
-    ConvW w; w.W = const_cast<void*>(Wk); w.bias = const_cast<float*>(bias); w.Cout = Cout; w.Ctot = C1 + C2; w.K = K;
+    ConvW w; w.W = const_cast<void*>(Wk); w.bias = const_cast<float*>(bias); w.Cout = Cout; w.Ctot = C1 + C2; w.K = K; w.Cin_real = C1 + C2;
     w.ldw = K; w.relu = relu;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == CV_DTYPE_F16 ? run_conv3<half_t>(src1, C1, src2, C2, w, out, out_f32, B, H, W, st)
@@ -916,5 +954,28 @@ extern "C" int cv_pp_debug_read(cv_pp* p, const char* name, void* host_dst, size
     if (bytes < need) { cva_set_error("need %zu bytes", need); return CV_ERR_INVALID; }
     CVA_CHECK_HIP(hipDeviceSynchronize());
     CVA_CHECK_HIP(hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+    return CV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling API
+// ------------------------------------------------------------------------------------------------
+extern "C" int cv_profile_enable(cv_handle* h, int on) {
+    if (!h) return CV_ERR_INVALID;
+    h->prof.on = on != 0;
+    return CV_OK;
+}
+
+// Synchronises; accumulates per class: total_ms[KC], launches[KC], flops[KC] (arrays of 5) and resets.
+extern "C" int cv_profile_collect(cv_handle* h, double* total_ms, int64_t* launches, double* flops) {
+    if (!h || !total_ms || !launches || !flops) return CV_ERR_INVALID;
+    for (int i = 0; i < KC_COUNT; ++i) { total_ms[i] = 0; launches[i] = 0; flops[i] = 0; }
+    CVA_CHECK_HIP(hipDeviceSynchronize());
+    for (auto& r : h->prof.recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { total_ms[r.cls] += ms; launches[r.cls] += 1; flops[r.cls] += r.flops; }
+        h->prof.pool.push_back(r.a); h->prof.pool.push_back(r.b);
+    }
+    h->prof.recs.clear();
     return CV_OK;
 }

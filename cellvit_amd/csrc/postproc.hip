@@ -395,7 +395,7 @@ constexpr int POOL_LDS = 1024;
 
 struct FloodParams {
     const double* dist; const uint8_t* blb; int* inst;       // [B][N]
-    const int* root1; const int* bb;                         // component labels + bboxes of the mask
+    const int* root1; const int* bb; const int* csize;      // component labels, bboxes, pixel counts of the mask
     const int* comp_list; const int* comp_count; int list_cap;
     int* queue_head;                                          // [B] dequeue cursors
     double* ovf_v; unsigned* ovf_age; int* ovf_idx; int* ovf_lab; unsigned long long* ovf_cursor;   // overflow arena [B][N]
@@ -441,6 +441,7 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
             const int root = p.comp_list[(long)tile * p.list_cap + ci];
             const int by0 = y0a[root], by1 = y1a[root], bx0 = x0a[root], bx1 = x1a[root];
             const int bw = bx1 - bx0 + 1, barea = bw * (by1 - by0 + 1);
+            const int carea = p.csize[base + root];   // pool entries never exceed the component's pixel count
             int n = 0;                 // pool size (wave uniform)
             long ovf_base = -1;        // lazily reserved slice of the overflow arena
             unsigned age = 0;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                 if (cnt == 0) return;
                 if (n + cnt > POOL_LDS && ovf_base < 0) {
                     unsigned long long o = 0;
-                    if (lane == 0) o = atomicAdd(&p.ovf_cursor[tile], (unsigned long long)barea);
+                    if (lane == 0) o = atomicAdd(&p.ovf_cursor[tile], (unsigned long long)carea);   // sum over components <= N
                     ovf_base = (long)__shfl((long long)o, 0);
                 }
                 if (have) {
@@ -820,7 +821,7 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     hipLaunchKernelGGL(k_marker_filter, grid, blk, 0, st, w->marker, w->msize, object_size, w->blb, inst_out, N, d.max_ids);
     // ---- P6: ordered flood ----
     FloodParams fp{};
-    fp.dist = w->dist; fp.blb = w->blb; fp.inst = inst_out; fp.root1 = w->L1; fp.bb = w->bb;
+    fp.dist = w->dist; fp.blb = w->blb; fp.inst = inst_out; fp.root1 = w->L1; fp.bb = w->bb; fp.csize = w->csize;
     fp.comp_list = w->comp_list; fp.comp_count = comp_count; fp.list_cap = w->list_cap; fp.queue_head = queue_head;
     fp.ovf_v = w->ovf_v; fp.ovf_age = w->ovf_age; fp.ovf_idx = w->ovf_idx; fp.ovf_lab = w->ovf_lab; fp.ovf_cursor = w->ovf_cursor;
     fp.H = H; fp.W = W; fp.B = B;

@@ -107,6 +107,12 @@ int cv_forward(cv_handle* h, const float* x_dev, int B, int H, int W, const cv_o
 int cv_set_debug(cv_handle* h, int enable);
 int cv_debug_read(cv_handle* h, const char* name, float* host_dst, size_t capacity, size_t* n_out);
 
+/* Live per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
+ * class while enabled).  Classes: 0 linear GEMM, 1 QKV GEMM, 2 conv3x3, 3 convT2x2, 4 attention.
+ * cv_profile_collect synchronises, fills three arrays of 5 (ms, launches, algorithmic FLOPs) and resets. */
+int cv_profile_enable(cv_handle* h, int on);
+int cv_profile_collect(cv_handle* h, double* total_ms, int64_t* launches, double* flops);
+
 /* ---- single-operator entry points (the -m gpu parity tests drive the kernels through these) ---- */
 /* out[M,N] = act(A[M,K] · W[N,K]^T + bias) (+ residual); A, W device buffers of `dtype`.              */
 int cv_op_linear(int dtype, const void* A, const void* W, const float* bias, const float* residual,

@@ -102,7 +102,7 @@ def test_batch_of_different_tiles():
 def test_dense_tile_large_components_overflow_pool():
     """Heavily overlapping nuclei -> few huge mask components: exercises the LDS-pool overflow arena."""
     from oracle import postproc_ref as P
-    tm, bm, hv, _ = synth_nuclei_maps(31, 512, 9000)
+    tm, bm, hv, _ = synth_nuclei_maps(31, 256, 9000)
     assert bm.mean() > 0.6
     inst, dicts, _ = _gpu_chain(tm, bm, hv, 40)
     pm = np.stack([tm.astype(np.float32), bm.astype(np.float32), hv[0], hv[1]], -1)
