@@ -85,6 +85,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64: import it FIRST so that this library binds to the same HIP
+    # runtime instance (two runtimes in one process do not share devices/streams).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build the HIP extension with `python -m cellvit_amd.build` "

@@ -1,0 +1,125 @@
+"""Tile-parallel execution across the GPUs of one node (one process per GPU, torch.distributed over
+RCCL/xGMI — backend "nccl" on ROCm — or gloo on CPU for tests).
+
+The hot path has no cross-tile state (reference hot loop: cell_detection.py:306-421), so tiles shard
+embarrassingly: a static block-cyclic split of the slide's row-major tile list, weights replicated,
+NO collective on the data path.  The only exchange is at the slide level: cells whose bounding box
+reaches into the 64-px overlap margin of their tile ("margin cells", get_cell_position_marging,
+cell_detection.py:820-874) may be detected twice by neighbouring tiles that live on different ranks;
+their fixed-size records are all-gathered (all_gather of counts, then of padded buffers — ~10-40 MB per
+gigapixel slide, latency-bound) so that every rank (or rank 0) can run the de-duplication.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# record layout (int32 columns / float64 columns)
+I_ROW, I_COL, I_RMIN, I_CMIN, I_RMAX, I_CMAX, I_TYPE, I_STATUS, I_EDGE, I_NPIX, I_CLEN, I_ID = range(12)
+F_CX, F_CY, F_PROB = range(3)
+N_ICOL, N_FCOL = 12, 3
+
+
+def shard_tiles(n_tiles: int, rank: int, world: int, block: int = 1) -> List[int]:
+    """Static block-cyclic assignment of tile indices (row-major order of wsi.patches_list) to ranks."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    out = []
+    for start in range(rank * block, n_tiles, world * block):
+        out.extend(range(start, min(start + block, n_tiles)))
+    return out
+
+
+def global_offset(row: int, col: int, patch_size: int, downsample: float, overlap: int) -> Tuple[int, int]:
+    """cell_detection.py:341-350: (x_global, y_global) offset of a tile on the highest magnification.
+    NB the reference names the ROW offset 'x_global' and adds the pair flipped to (x, y) quantities."""
+    xg = int(row * patch_size * downsample - (row + 0.5) * overlap)
+    yg = int(col * patch_size * downsample - (col + 0.5) * overlap)
+    return xg, yg
+
+
+def cell_edge_position(bbox: np.ndarray, patch_size: int = 1024) -> List[int]:
+    """get_cell_position (cell_detection.py:787-817): [top, right, down, left] flags of a bbox
+    [[rmin, cmin], [rmax, cmax]] touching the tile border."""
+    return [int(bbox[0, 0] == 0), int(bbox[1, 1] == patch_size), int(bbox[1, 0] == patch_size), int(bbox[0, 1] == 0)]
+
+
+def cell_status(bbox: np.ndarray, patch_size: int = 1024, margin: int = 64) -> int:
+    """get_cell_position_marging (cell_detection.py:820-874): 0 = mid, 1..8 clockwise from top-left."""
+    lo, hi = margin, patch_size - margin
+    if not (np.max(bbox) > hi or np.min(bbox) < lo):
+        return 0
+    top, left = bbox[0, 0] < lo, bbox[0, 1] < lo
+    down, right = bbox[1, 0] > hi, bbox[1, 1] > hi
+    if top:
+        return 1 if left else (3 if right else 2)
+    if right:
+        return 5 if down else 4
+    if down:
+        return 7 if left else 6
+    if left:
+        return 8
+    return None   # unreachable for well-formed boxes (mirrors the reference's fall-through)
+
+
+_EDGE_TABLE = {   # get_edge_patch (cell_detection.py:877-902): position -> neighbour tile offsets (drow, dcol)
+    (1, 0, 0, 0): [(-1, 0)], (1, 1, 0, 0): [(-1, 0), (-1, 1), (0, 1)], (0, 1, 0, 0): [(0, 1)],
+    (0, 1, 1, 0): [(0, 1), (1, 1), (1, 0)], (0, 0, 1, 0): [(1, 0)], (0, 0, 1, 1): [(1, 0), (1, -1), (0, -1)],
+    (0, 0, 0, 1): [(0, -1)], (1, 0, 0, 1): [(0, -1), (-1, -1), (-1, 0)],
+}
+
+
+def edge_patches(position: Sequence[int], row: int, col: int):
+    offs = _EDGE_TABLE.get(tuple(int(p) for p in position))
+    return None if offs is None else [[row + dr, col + dc] for dr, dc in offs]
+
+
+def pack_margin_records(tile_dict: dict, row: int, col: int, patch_size: int = 1024, margin: int = 64):
+    """Per-tile nucleus dict (post_proc:126-151 layout) -> (int32 [n,12], float64 [n,3], int32 [m,2]) arrays of
+    the cells that are NOT safely in the tile centre (status != 0) — the only ones that need an exchange."""
+    irows, frows, contours = [], [], []
+    for cid, c in tile_dict.items():
+        st = cell_status(c["bbox"], patch_size, margin)
+        if st == 0:
+            continue
+        bb = c["bbox"]
+        edge = int(np.max(bb) == patch_size or np.min(bb) == 0)
+        cont = c["contour"] if c.get("contour") is not None else np.zeros((0, 2), np.int32)
+        irows.append([row, col, bb[0, 0], bb[0, 1], bb[1, 0], bb[1, 1], c["type"], st, edge, 0, len(cont), cid])
+        frows.append([c["centroid"][0], c["centroid"][1], c["type_prob"]])
+        contours.append(np.asarray(cont, np.int32).reshape(-1, 2))
+    ir = np.asarray(irows, np.int32).reshape(-1, N_ICOL)
+    fr = np.asarray(frows, np.float64).reshape(-1, N_FCOL)
+    ct = np.concatenate(contours).astype(np.int32) if contours else np.zeros((0, 2), np.int32)
+    return ir, fr, ct
+
+
+def _all_gather_var(t: torch.Tensor, group=None) -> List[torch.Tensor]:
+    """all-gatherv: gather counts, pad to the maximum, gather, trim.  Works on nccl (device tensors) and gloo."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts + [1])
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return [b[:c] for b, c in zip(bufs, counts)]
+
+
+def all_gather_margin_records(ir: np.ndarray, fr: np.ndarray, ct: np.ndarray, device=None, group=None):
+    """Exchange the margin-cell records of all ranks (rank order preserved).  Returns the concatenated
+    (int32 [N,12], float64 [N,3], int32 [M,2]) arrays; contour slices follow the record order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return ir, fr, ct
+    dev = device or torch.device("cpu")
+    parts_i = _all_gather_var(torch.from_numpy(np.ascontiguousarray(ir)).to(dev), group)
+    parts_f = _all_gather_var(torch.from_numpy(np.ascontiguousarray(fr)).to(dev), group)
+    parts_c = _all_gather_var(torch.from_numpy(np.ascontiguousarray(ct)).to(dev), group)
+    cat = lambda ps: torch.cat(ps).cpu().numpy()   # noqa: E731
+    return cat(parts_i), cat(parts_f), cat(parts_c)
