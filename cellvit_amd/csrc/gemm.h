@@ -40,6 +40,7 @@ struct GemmParams {
     void* q_out; void* k_out; void* vt_out;
     int D, hd, heads, ntok, L, Lp;   // ntok tokens per image (incl. cls for ViT)
     int win, gw, gh, nwx, nwy;       // win > 0: window partition of the gh x gw token grid
+    const void* zero;                // >= 16 B of zeros in device memory (filled in by launch_gemm)
 };
 
 template <typename T> int launch_gemm(const GemmParams& p, int a_mode, hipStream_t stream);

@@ -7,11 +7,83 @@
 // registers while the current one is multiplied.
 #include "gemm.h"
 
+#include <stdlib.h>
+
 namespace cva {
 
 namespace {
 
 constexpr int BM = 128, BN = 128, NT = 256;
+
+// C fragment layout: lane l, reg r -> row (l>>4)*4 + r, col l&15.  rowb/colb: this lane's first row / col.
+template <typename T, int OMODE>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], const int rowb, const int colb) {
+    using TR = Traits<T>;
+    T* outT = reinterpret_cast<T*>(p.out);
+    float* outF = reinterpret_cast<float*>(p.out);
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = colb + j * 16;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+        // column-dependent scatter terms
+        long col_term = 0; int which = 0;
+        if (OMODE == OUT_QKV) {
+            which = n / p.D;
+            const int c = n - which * p.D;
+            const int h = c / p.hd, d = c - h * p.hd;
+            // q,k: ((s*heads+h)*L + pos)*hd + d ; vt: ((s*heads+h)*hd + d)*Lp + pos
+            col_term = (which < 2) ? ((long)h * p.L * p.hd + d) : (((long)h * p.hd + d) * p.Lp);
+        } else if (OMODE == OUT_CONVT) {
+            const int cout = p.N >> 2;
+            const int dd = n / cout, co = n - dd * cout;
+            const int dy = dd >> 1, dx = dd & 1;
+            col_term = ((long)dy * (2 * p.Wd) + dx) * cout + co;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = rowb + i * 16 + r;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (p.act == ACT_GELU) v = gelu_erf(v);
+                else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                if (OMODE == OUT_LINEAR) {
+                    long orow = m;
+                    if (p.o_rpi > 0) orow = (long)m + (long)(m / p.o_rpi) * p.o_extra + p.o_off;
+                    if (p.res) {
+                        const long rrow = p.res_mod > 0 ? (long)(m % p.res_mod) : orow;
+                        v += p.res[rrow * p.ldres + n];
+                    }
+                    const long o = orow * (long)p.ldc + n;
+                    if (p.out_f32) outF[o] = v; else outT[o] = TR::from_float(v);
+                } else if (OMODE == OUT_CONVT) {
+                    const int hw = p.H * p.Wd;
+                    const int b = m / hw, rr = m - b * hw;
+                    const int y = rr / p.Wd, x = rr - y * p.Wd;
+                    const int cout = p.N >> 2;
+                    const long o = (((long)b * 2 * p.H + 2 * y) * (2 * p.Wd) + 2 * x) * cout + col_term;
+                    if (p.out_f32) outF[o] = v; else outT[o] = TR::from_float(v);
+                } else {  // OUT_QKV
+                    const int b = m / p.ntok, t = m - b * p.ntok;
+                    int s = b, pos = t;
+                    if (p.win > 0) {
+                        const int gy = t / p.gw, gx = t - gy * p.gw;
+                        const int wy = gy / p.win, wx = gx / p.win;
+                        s = (b * p.nwy + wy) * p.nwx + wx;
+                        pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
+                    }
+                    const T tv = TR::from_float(v);
+                    if (which == 0) reinterpret_cast<T*>(p.q_out)[((long)s * p.heads * p.L + pos) * p.hd + col_term] = tv;
+                    else if (which == 1) reinterpret_cast<T*>(p.k_out)[((long)s * p.heads * p.L + pos) * p.hd + col_term] = tv;
+                    else reinterpret_cast<T*>(p.vt_out)[(long)s * p.heads * p.hd * p.Lp + col_term + pos] = tv;
+                }
+            }
+        }
+    }
+}
 
 template <typename T, int AMODE, int OMODE>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
@@ -128,82 +200,227 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    // ------------------------------------------------------------------ epilogue
-    // C fragment layout: lane l, reg r -> row (l>>4)*4 + r, col l&15.
-    const int colb = n0 + wn * 64 + (lane & 15);
-    const int rowb = m0 + wm * 64 + (lane >> 4) * 4;
-    T* outT = reinterpret_cast<T*>(p.out);
-    float* outF = reinterpret_cast<float*>(p.out);
+    gemm_epilogue<T, OMODE>(p, acc, m0 + wm * 64 + (lane >> 4) * 4, n0 + wn * 64 + (lane & 15));
+}
 
+
+// ================================================================================================
+// v2: direct-to-LDS staging (global_load_lds dwordx4), XOR-swizzled 128-byte rows, double-buffered.
+//
+// Each 1-KiB wave-instruction lands 8 tile rows x 128 B linearly in LDS (destination = wave-uniform
+// base + lane*16).  The bank-conflict fix therefore goes on the SOURCE address: lane l fetches the
+// logical 16-B piece (l&7) ^ ((row>>1)&7) of its row, and fragment reads apply the same involution.
+// With 128-B rows two rows share one 256-B bank row, so XOR-ing with (row>>1)&7 spreads the 16 rows
+// of every ds_read_b128 lane group over all 16 slots.  The permutation stays inside
+// one 128-B line: global coalescing is unchanged.  Out-of-range rows / K tail read a zero page.
+// One barrier per K tile; the next tile's DMA is in flight while the current one is multiplied.
+// ================================================================================================
+template <typename T, int AMODE, int OMODE, int WM>
+__global__ __launch_bounds__(WM * 128, 1) void gemm_glds_kernel(const GemmParams p) {
+    using TR = Traits<T>;
+    constexpr int BK = TR::BK, PE = TR::PIECE;
+    constexpr int TBM = WM * 64, TBN = 128, NTH = WM * 128, NW = NTH / 64;
+    constexpr int ROWB = 128;                         // bytes per tile row
+    constexpr int A_CHUNKS = TBM / 8, B_CHUNKS = TBN / 8;   // 1-KiB chunks (8 rows each)
+    constexpr int A_PER_WAVE = A_CHUNKS / NW, B_PER_WAVE = B_CHUNKS / NW;
+    constexpr int KSTEPS = BK / 32;
+    constexpr int BUF_BYTES = (TBM + TBN) * ROWB;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + TBN - 1) / TBN, tiles_m = (p.M + TBM - 1) / TBM;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (bid / tiles_n) * TBM, n0 = (bid % tiles_n) * TBN;
+
+    const T* __restrict__ Ap = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ A2p = reinterpret_cast<const T*>(p.A2);
+    const T* __restrict__ Wp = reinterpret_cast<const T*>(p.W);
+    const T* __restrict__ Zp = reinterpret_cast<const T*>(p.zero);
+
+    // ---- per-lane descriptors of the rows this lane stages (fixed over the K loop) ----
+    const int lrow = lane >> 3;                  // row inside the 8-row chunk
+    const int lpc = lane & 7;                    // physical 16-B piece inside the row
+    long a_off[A_PER_WAVE]; int a_b[A_PER_WAVE], a_y[A_PER_WAVE], a_x[A_PER_WAVE], a_lp[A_PER_WAVE];
+    bool a_ok[A_PER_WAVE];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = colb + j * 16;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-        // column-dependent scatter terms
-        long col_term = 0; int which = 0;
-        if (OMODE == OUT_QKV) {
-            which = n / p.D;
-            const int c = n - which * p.D;
-            const int h = c / p.hd, d = c - h * p.hd;
-            // q,k: ((s*heads+h)*L + pos)*hd + d ; vt: ((s*heads+h)*hd + d)*Lp + pos
-            col_term = (which < 2) ? ((long)h * p.L * p.hd + d) : (((long)h * p.hd + d) * p.Lp);
-        } else if (OMODE == OUT_CONVT) {
-            const int cout = p.N >> 2;
-            const int dd = n / cout, co = n - dd * cout;
-            const int dy = dd >> 1, dx = dd & 1;
-            col_term = ((long)dy * (2 * p.Wd) + dx) * cout + co;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = rowb + i * 16 + r;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (p.act == ACT_GELU) v = gelu_erf(v);
-                else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                if (OMODE == OUT_LINEAR) {
-                    long orow = m;
-                    if (p.o_rpi > 0) orow = (long)m + (long)(m / p.o_rpi) * p.o_extra + p.o_off;
-                    if (p.res) {
-                        const long rrow = p.res_mod > 0 ? (long)(m % p.res_mod) : orow;
-                        v += p.res[rrow * p.ldres + n];
-                    }
-                    const long o = orow * (long)p.ldc + n;
-                    if (p.out_f32) outF[o] = v; else outT[o] = TR::from_float(v);
-                } else if (OMODE == OUT_CONVT) {
-                    const int hw = p.H * p.Wd;
-                    const int b = m / hw, rr = m - b * hw;
-                    const int y = rr / p.Wd, x = rr - y * p.Wd;
-                    const int cout = p.N >> 2;
-                    const long o = (((long)b * 2 * p.H + 2 * y) * (2 * p.Wd) + 2 * x) * cout + col_term;
-                    if (p.out_f32) outF[o] = v; else outT[o] = TR::from_float(v);
-                } else {  // OUT_QKV
-                    const int b = m / p.ntok, t = m - b * p.ntok;
-                    int s = b, pos = t;
-                    if (p.win > 0) {
-                        const int gy = t / p.gw, gx = t - gy * p.gw;
-                        const int wy = gy / p.win, wx = gx / p.win;
-                        s = (b * p.nwy + wy) * p.nwx + wx;
-                        pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
-                    }
-                    const T tv = TR::from_float(v);
-                    if (which == 0) reinterpret_cast<T*>(p.q_out)[((long)s * p.heads * p.L + pos) * p.hd + col_term] = tv;
-                    else if (which == 1) reinterpret_cast<T*>(p.k_out)[((long)s * p.heads * p.L + pos) * p.hd + col_term] = tv;
-                    else reinterpret_cast<T*>(p.vt_out)[(long)s * p.heads * p.hd * p.Lp + col_term + pos] = tv;
-                }
-            }
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int row = (wave * A_PER_WAVE + i) * 8 + lrow;
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        a_lp[i] = lpc ^ ((row >> 1) & 7);        // logical piece this lane must fetch
+        if (AMODE == A_LINEAR) {
+            long r = m;
+            if (p.a_rpi > 0) r = (long)m + (long)(m / p.a_rpi) * p.a_extra + p.a_off;
+            a_off[i] = r * (long)p.lda;
+            a_b[i] = a_y[i] = a_x[i] = 0;
+        } else {
+            const int hw = p.H * p.Wd;
+            const int b = m / hw, r = m - b * hw;
+            a_b[i] = b; a_y[i] = r / p.Wd; a_x[i] = r - a_y[i] * p.Wd; a_off[i] = 0;
         }
     }
+    long w_off[B_PER_WAVE]; int w_lp[B_PER_WAVE]; bool w_ok[B_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) {
+        const int row = (wave * B_PER_WAVE + i) * 8 + lrow;
+        const int n = n0 + row;
+        w_ok[i] = n < p.N;
+        w_lp[i] = lpc ^ ((row >> 1) & 7);
+        w_off[i] = (long)n * p.ldw;
+    }
+    const int ctot = p.C1 + p.C2;
+    const int ppt = (AMODE == A_CONV3) ? ctot / PE : 1;
+
+    auto stage = [&](int kt, int buf) {
+        unsigned char* sA = smem_raw + buf * BUF_BYTES;
+        unsigned char* sB = sA + TBM * ROWB;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i) {
+            const T* src = Zp;
+            const int k = k0 + a_lp[i] * PE;
+            if (AMODE == A_LINEAR) {
+                if (a_ok[i] && k < p.K) src = Ap + a_off[i] + k;
+            } else {
+                const int q = k / PE;
+                const int tap = q / ppt;
+                const int c = (q - tap * ppt) * PE;
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+                if (tap < 9 && a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd) {
+                    const bool second = c >= p.C1;
+                    const T* base = second ? A2p : Ap;
+                    const int cs = second ? p.C2 : p.C1;
+                    src = base + ((long)(a_b[i] * p.H + yy) * p.Wd + xx) * cs + (second ? c - p.C1 : c);
+                }
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sA + (wave * A_PER_WAVE + i) * 1024),
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_WAVE; ++i) {
+            const T* src = w_ok[i] ? Wp + w_off[i] + k0 + w_lp[i] * PE : Zp;   // W rows are zero padded to ldw
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sB + (wave * B_PER_WAVE + i) * 1024),
+                                             16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+
+    // fragment read addressing: row r, logical piece lp -> byte r*128 + ((lp ^ ((r>>1)&7)) << 4)
+    const int g = lane >> 4;
+    int a_row[4], b_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a_row[i] = wm * 64 + i * 16 + (lane & 15); b_row[i] = wn * 64 + i * 16 + (lane & 15); }
+
+    auto load_frag = [&](const unsigned char* base, int row, int ks) -> typename TR::Frag {
+        const int sw = (row >> 1) & 7;
+        if constexpr (sizeof(T) == 2) {
+            const int lp = ks * 4 + g;
+            return TR::load_frag(reinterpret_cast<const T*>(base + row * ROWB + ((lp ^ sw) << 4)));
+        } else {
+            typename TR::Frag f;
+            const int lp = 2 * g;    // BK = 32 floats: one k-step spans the whole row
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(base + row * ROWB + ((lp ^ sw) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(base + row * ROWB + (((lp + 1) ^ sw) << 4));
+            f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3];
+            f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+            return f;
+        }
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const unsigned char* sA = smem_raw + buf * BUF_BYTES;
+        const unsigned char* sB = sA + TBM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            typename TR::Frag a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = load_frag(sA, a_row[i], ks);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = load_frag(sB, b_row[j], ks);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) TR::mma(a[i], b[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    gemm_epilogue<T, OMODE>(p, acc, m0 + wm * 64 + (lane >> 4) * 4, n0 + wn * 64 + (lane & 15));
 }
 
 }  // namespace
 
+namespace {
+void* zero_page() {   // 256 B of zeros: the DMA source of out-of-range pieces
+    static void* z = nullptr;
+    if (!z) { if (hipMalloc(&z, 256) != hipSuccess) return nullptr; (void)hipMemset(z, 0, 256); }
+    return z;
+}
+int gemm_variant() {   // CVA_GEMM=1: register-staged v1; 2 (default): 128x128 glds; 3: 256x128 glds
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CVA_GEMM"); v = e ? atoi(e) : 2; if (v < 1 || v > 3) v = 2; }
+    return v;
+}
+template <typename T, int AMODE, int OMODE, int WM>
+int launch_glds(const GemmParams& p, hipStream_t stream) {
+    constexpr int TBM = WM * 64, TBN = 128;
+    const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
+    const size_t lds = 2 * (size_t)(TBM + TBN) * 128;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AMODE, OMODE, WM>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return (int)hipGetLastError();
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_glds_kernel<T, AMODE, OMODE, WM>), dim3(tiles), dim3(WM * 128), lds, stream, p);
+    return (int)hipGetLastError();
+}
+template <typename T, int WM>
+int dispatch_glds(const GemmParams& p, int a_mode, hipStream_t stream) {
+    if (a_mode == A_CONV3) {
+        if (p.out_mode != OUT_LINEAR) return (int)hipErrorInvalidValue;
+        return launch_glds<T, A_CONV3, OUT_LINEAR, WM>(p, stream);
+    }
+    if (p.out_mode == OUT_LINEAR) return launch_glds<T, A_LINEAR, OUT_LINEAR, WM>(p, stream);
+    if (p.out_mode == OUT_QKV) return launch_glds<T, A_LINEAR, OUT_QKV, WM>(p, stream);
+    return launch_glds<T, A_LINEAR, OUT_CONVT, WM>(p, stream);
+}
+}  // namespace
+
 template <typename T>
-int launch_gemm(const GemmParams& p, int a_mode, hipStream_t stream) {
+int launch_gemm(const GemmParams& p_in, int a_mode, hipStream_t stream) {
+    GemmParams p = p_in;
+    if (((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) <= 0) return 0;
+    const int variant = gemm_variant();
+    if (variant >= 2) {
+        p.zero = zero_page();
+        if (!p.zero) return (int)hipErrorOutOfMemory;
+        // DMA pieces are whole 16-B units: the linear A operand needs 16-B aligned rows
+        const bool aligned = a_mode == A_CONV3 || ((size_t)p.lda * sizeof(T)) % 16 == 0;
+        if (aligned) {
+            // 256-row tiles only pay when the grid still fills the chip
+            const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+            if (variant == 3 && tiles256 >= 512) return dispatch_glds<T, 4>(p, a_mode, stream);
+            return dispatch_glds<T, 2>(p, a_mode, stream);
+        }
+    }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    if (tiles <= 0) return 0;
     const dim3 g(tiles), b(NT);
     if (a_mode == A_CONV3) {
         if (p.out_mode != OUT_LINEAR) return (int)hipErrorInvalidValue;
