@@ -13,6 +13,8 @@ struct AttnParams {
     const void* Q; const void* K; const void* Vt;   // T
     const float* relh;      // [S*heads, L, KH] fp32 or null
     const float* relw;      // [S*heads, L, KW]
+    const float* tab_h;     // fused path (attention2): raw tables [2*KH-1, hd] / [2*KW-1, hd] fp32, or null
+    const float* tab_w;
     void* out;              // T [tokens, D]
     int S, heads, L, Lp, hd, D;
     int nk;                 // number of keys (== L)
@@ -38,6 +40,8 @@ struct PadKVParams {        // window mode: keys/values of zero-padded tokens ar
 };
 
 template <typename T> int launch_attention(const AttnParams& p, hipStream_t stream);
+// v2 (attention2.hip): fused rel-pos; returns -1 when the geometry is not covered (caller uses v1 + launch_relpos)
+template <typename T> int launch_attention2(const AttnParams& p, hipStream_t stream);
 template <typename T> int launch_relpos(const RelPosParams& p, hipStream_t stream);
 template <typename T> int launch_pad_kv(const PadKVParams& p, hipStream_t stream);
 

@@ -1,0 +1,363 @@
+// Attention v2 for gfx950: transposed flash attention with the decomposed relative-position bias
+// fused in (no separate rel-pos kernel, no bias tables in HBM).
+//
+//   S^T = K · Q^T   (A = K tile rows, B = Q rows)   -> lane l holds keys g*4+r of ONE query (l&15):
+//                                                     the softmax row reductions are lane-local + 2 shuffles
+//   O^T = V^T · P^T (A = V^T rows,   B = P^T)       -> P^T is consumed straight from the S^T registers
+//                                                     (the contraction index is re-labelled so that the
+//                                                     C-fragment of S^T IS the B-fragment of P^T);
+//                                                     accumulators keep the same lane<->query map, so the
+//                                                     running max / sum / rescale never cross lanes.
+// One workgroup = 4 waves x 32 queries (2 query blocks of 16) of one (sequence, head); K and V^T tiles
+// of 64 keys are staged through LDS and shared by the 8 query blocks.
+//
+// Decomposed rel-pos (SAM/image_encoder.py:354-392): bias[q,(kh,kw)] = q·Rh[qy-kh+KH-1] + q·Rw[qx-kw+KW-1].
+// At block start each wave computes G = Q·tab^T for its 32 queries with MFMAs and scatters the needed
+// diagonal band into an LDS table relcat[q][0..KH) ++ [KH..KH+KW) (pre-divided by the softmax scale).
+//   BIAS 1 (KH+KW <= 64: windows, small tiles): the bias is one or two extra contraction steps of the
+//          S^T MFMA against a per-tile one-hot matrix E[key][kh | KH+kw] — no per-element lookups.
+//   BIAS 2 (KW == 64 == key tile: 1024-px tiles, global blocks): kh is constant per key tile (one LDS
+//          scalar per query and tile), the kw term is tile-invariant and lives in registers.
+#include "attention.h"
+
+namespace cva {
+
+namespace {
+
+constexpr int KT = 64, NT = 256, QW = 32, QT = 128;
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <typename T> struct Pack4;   // 4 consecutive T elements
+template <> struct Pack4<half_t> { typedef _Float16 type __attribute__((ext_vector_type(4))); };
+template <> struct Pack4<float> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <typename T>
+__device__ __forceinline__ void set_frag(typename Traits<T>::Frag& f, int j, float v);
+template <>
+__device__ __forceinline__ void set_frag<half_t>(Traits<half_t>::Frag& f, int j, float v) { f.v[j] = (half_t)v; }
+template <>
+__device__ __forceinline__ void set_frag<float>(Traits<float>::Frag& f, int j, float v) { f.v[j] = v; }
+
+template <typename T>
+__device__ __forceinline__ typename Traits<T>::Frag frag_from_2x4(const T* p0, const T* p1) {
+    typename Traits<T>::Frag f;
+    const typename Pack4<T>::type a = *reinterpret_cast<const typename Pack4<T>::type*>(p0);
+    const typename Pack4<T>::type b = *reinterpret_cast<const typename Pack4<T>::type*>(p1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+    return f;
+}
+
+template <typename T, int HD, int BIAS, int NBK>
+__global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
+    using TR = Traits<T>;
+    using Frag = typename TR::Frag;
+    constexpr int PE = TR::PIECE;
+    constexpr int HDP = (HD + 31) / 32 * 32, NKS = HDP / 32, ND = HD / 16;
+    constexpr int PK = lds_pitch<T>(HDP), PV = lds_pitch<T>(KT);
+    constexpr int EW = NBK * 32;                       // one-hot width (BIAS 1)
+    constexpr int PE1 = lds_pitch<T>(EW);              // pitch of E and relcat rows (BIAS 1)
+    constexpr int RC2 = 128 + 8;                       // relcat row pitch (BIAS 2): KH + KW <= 128
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);            // [KT][PK]
+    T* Vts = Ks + KT * PK;                             // [HD][PV]
+    T* Es = Vts + HD * PV;                             // BIAS 1: [KT][PE1]
+    T* Rc = Es + (BIAS == 1 ? KT * PE1 : 0);           // relcat: BIAS 1 [QT][PE1], BIAS 2 [QT][RC2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int q0 = blockIdx.x * QT + wave * QW;         // first query of this wave
+    const int sh = blockIdx.y;
+
+    const T* __restrict__ Qg = reinterpret_cast<const T*>(p.Q) + (long)sh * p.L * HD;
+    const T* __restrict__ Kg = reinterpret_cast<const T*>(p.K) + (long)sh * p.L * HD;
+    const T* __restrict__ Vg = reinterpret_cast<const T*>(p.Vt) + (long)sh * HD * p.Lp;
+
+    if (HDP > HD) {
+        for (int i = tid; i < KT * (HDP - HD); i += NT) {
+            const int r = i / (HDP - HD), c = i - r * (HDP - HD);
+            Ks[r * PK + HD + c] = TR::from_float(0.f);
+        }
+    }
+
+    // ---- Q fragments (B operand of S^T): lane -> query li of block qb, head-dim slice g*8.. ----
+    Frag qf[2][NKS];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int row = q0 + qb * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d0 = ks * 32 + g * 8;
+            qf[qb][ks] = (row < p.L && d0 < HD) ? TR::load_frag(Qg + (long)row * HD + d0) : TR::zero_frag();
+        }
+    }
+
+    // ---- decomposed rel-pos: relcat[q][kh] = q·tab_h[qy-kh+KH-1] / scale ; relcat[q][KH+kw] likewise ----
+    const float inv_scale = 1.0f / p.scale;
+    if (BIAS != 0) {
+        constexpr int RCP = (BIAS == 1) ? PE1 : RC2;
+        T* myrc = Rc + (wave * QW) * RCP;
+        for (int i = lane; i < QW * RCP; i += 64) myrc[i] = TR::from_float(0.f);
+#pragma unroll 1
+        for (int tbl = 0; tbl < 2; ++tbl) {
+            const float* __restrict__ tab = tbl == 0 ? p.tab_h : p.tab_w;
+            const int Ksz = tbl == 0 ? p.KH : p.KW;
+            const int off = tbl == 0 ? 0 : p.KH;
+            const int nj = 2 * Ksz - 1;
+#pragma unroll 1
+            for (int jb = 0; jb * 16 < nj; ++jb) {
+                Frag tf[NKS];
+                const int j = jb * 16 + li;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const int d0 = ks * 32 + g * 8;
+                    tf[ks] = TR::zero_frag();
+                    if (j < nj && d0 < HD) {
+                        const float* src = tab + (long)j * HD + d0;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) set_frag<T>(tf[ks], e, src[e]);
+                    }
+                }
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    f32x4 acc = (f32x4)(0.f);
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) TR::mma(tf[ks], qf[qb][ks], acc);
+                    // acc[r] = q(li) · tab[jb*16 + g*4 + r]
+                    const int q = q0 + qb * 16 + li;
+                    if (q < p.L) {
+                        const int qy = q / p.KW, qx = q - qy * p.KW;
+                        const int c = tbl == 0 ? qy : qx;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int jj = jb * 16 + g * 4 + r;
+                            const int kk = c - jj + Ksz - 1;          // image_encoder.py:347-351
+                            if (jj < nj && kk >= 0 && kk < Ksz)
+                                myrc[(qb * 16 + li) * RCP + off + kk] = TR::from_float(acc[r] * inv_scale);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // BIAS 1: Q-side bias fragments (rows of relcat);  BIAS 2: tile-invariant kw terms in registers
+    Frag bf[2][NBK];
+    float bw[2][4][4];
+    if (BIAS == 1) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb2 = 0; kb2 < NBK; ++kb2)
+                bf[qb][kb2] = TR::load_frag(Rc + (wave * QW + qb * 16 + li) * PE1 + kb2 * 32 + g * 8);
+    } else if (BIAS == 2) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    bw[qb][kb][r] = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + p.KH + kb * 16 + g * 4 + r]) * p.scale;
+    }
+
+    f32x4 o[2][ND];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int n = 0; n < ND; ++n) o[qb][n] = (f32x4)(0.f);
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    const int ntiles = (p.nk + KT - 1) / KT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        {   // K tile
+            constexpr int PPR = HD / PE;
+            for (int i = tid; i < KT * PPR; i += NT) {
+                const int r = i / PPR, c = i - r * PPR;
+                const int key = kt * KT + r;
+                store_piece(Ks + r * PK + c * PE, key < p.nk ? load_piece(Kg + (long)key * HD + c * PE) : zero_piece());
+            }
+        }
+        {   // V^T tile
+            constexpr int PPR = KT / PE;
+            for (int i = tid; i < HD * PPR; i += NT) {
+                const int d = i / PPR, c = i - d * PPR;
+                const int key0 = kt * KT + c * PE;
+                Piece v = load_piece(Vg + (long)d * p.Lp + key0);
+                if (key0 + PE > p.nk) {
+                    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+                    for (int j = 0; j < PE; ++j) if (key0 + j >= p.nk) e[j] = TR::from_float(0.f);
+                }
+                store_piece(Vts + d * PV + c * PE, v);
+            }
+        }
+        if (BIAS == 1) {   // one-hot rows E[key][kh] = E[key][KH + kw] = 1
+            constexpr int PPR = EW / PE;
+            for (int i = tid; i < KT * PPR; i += NT) {
+                const int r = i / PPR, c = i - r * PPR;
+                const int key = kt * KT + r;
+                const int kh = key / p.KW, kw = key - kh * p.KW;
+                Piece v = zero_piece();
+                if (key < p.nk) {
+                    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+                    for (int j = 0; j < PE; ++j) {
+                        const int col = c * PE + j;
+                        if (col == kh || col == p.KH + kw) e[j] = TR::from_float(1.f);
+                    }
+                }
+                store_piece(Es + r * PE1 + c * PE, v);
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T blocks: s[qb][kb][r] = score(query li of qb, key kb*16 + g*4 + r) / scale ----
+        f32x4 s[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            s[0][kb] = (f32x4)(0.f); s[1][kb] = (f32x4)(0.f);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const Frag kf = TR::load_frag(Ks + (kb * 16 + li) * PK + ks * 32 + g * 8);
+                TR::mma(kf, qf[0][ks], s[0][kb]);
+                TR::mma(kf, qf[1][ks], s[1][kb]);
+            }
+            if (BIAS == 1) {
+#pragma unroll
+                for (int kb2 = 0; kb2 < NBK; ++kb2) {
+                    const Frag ef = TR::load_frag(Es + (kb * 16 + li) * PE1 + kb2 * 32 + g * 8);
+                    TR::mma(ef, bf[0][kb2], s[0][kb]);
+                    TR::mma(ef, bf[1][kb2], s[1][kb]);
+                }
+            }
+        }
+        // ---- online softmax per query (lane-local + the 4 lanes li, li+16, li+32, li+48) ----
+        Frag pf[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float bh = 0.f;
+            if (BIAS == 2) bh = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + kt]) * p.scale;   // kh == kt
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * KT + kb * 16 + g * 4 + r;
+                    float v = s[qb][kb][r] * p.scale;
+                    if (BIAS == 2) v += bw[qb][kb][r] + bh;
+                    v = key < p.nk ? v : -INFINITY;
+                    s[qb][kb][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m_run[qb], mx);
+            const float alpha = exp2f((m_run[qb] - mn) * LOG2E);
+            m_run[qb] = mn;
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2f((s[qb][kb][r] - mn) * LOG2E);
+                    rs += pv;
+                    // contraction slot (m, g*8 + j): j < 4 -> key block 2m, reg j ; j >= 4 -> key block 2m+1, reg j-4
+                    set_frag<T>(pf[qb][kb >> 1], (kb & 1) * 4 + r, pv);
+                }
+            rs += __shfl_xor(rs, 16);
+            rs += __shfl_xor(rs, 32);
+            l_run[qb] = l_run[qb] * alpha + rs;
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qb][n][r] *= alpha;
+        }
+        // ---- O^T += V^T P^T : A = V^T rows d = n*16 + li, keys (2m)*16 + g*4 + {0..3} and (2m+1)*16 + g*4 + {0..3} ----
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int n = 0; n < ND; ++n) {
+                const T* vrow = Vts + (n * 16 + li) * PV + g * 4;
+                const Frag vf = frag_from_2x4<T>(vrow + (2 * m) * 16, vrow + (2 * m + 1) * 16);
+                TR::mma(vf, pf[0][m], o[0][n]);
+                TR::mma(vf, pf[1][m], o[1][n]);
+            }
+        }
+    }
+
+    // ---- normalise; lane holds O[query li of qb][d = n*16 + g*4 + r] ----
+    const int s_idx = sh / p.heads, h = sh - s_idx * p.heads;
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qg = q0 + qb * 16 + li;
+        if (qg >= p.L) continue;
+        long row;
+        if (p.win > 0) {
+            const int nw = p.nwx * p.nwy;
+            const int b = s_idx / nw, w = s_idx - b * nw;
+            const int wy = w / p.nwx, wx = w - wy * p.nwx;
+            const int py = qg / p.win, px = qg - py * p.win;
+            const int gy = wy * p.win + py, gx = wx * p.win + px;
+            if (gy >= p.gh || gx >= p.gw) continue;
+            row = (long)b * p.ntok + gy * p.gw + gx;
+        } else {
+            row = (long)s_idx * p.ntok + qg;
+        }
+        const float inv = 1.0f / l_run[qb];
+#pragma unroll
+        for (int n = 0; n < ND; ++n) {
+            typename Pack4<T>::type v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = TR::from_float(o[qb][n][r] * inv);
+            *reinterpret_cast<typename Pack4<T>::type*>(out + row * p.D + h * HD + n * 16 + g * 4) = v;
+        }
+    }
+}
+
+template <typename T, int HD, int BIAS, int NBK>
+int launch_attn2_impl(const AttnParams& p, hipStream_t stream) {
+    constexpr int HDP = (HD + 31) / 32 * 32;
+    size_t lds = (size_t)(KT * lds_pitch<T>(HDP) + HD * lds_pitch<T>(KT)) * sizeof(T);
+    if (BIAS == 1) lds += (size_t)(KT + QT) * lds_pitch<T>(NBK * 32) * sizeof(T);
+    if (BIAS == 2) lds += (size_t)QT * (128 + 8) * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<T, HD, BIAS, NBK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((p.L + QT - 1) / QT, p.S * p.heads);
+    hipLaunchKernelGGL((attn2_kernel<T, HD, BIAS, NBK>), grid, dim3(NT), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int HD>
+int launch_attn2_hd(const AttnParams& p, hipStream_t stream) {
+    if (!p.tab_h) return launch_attn2_impl<T, HD, 0, 1>(p, stream);
+    if (p.KW == KT && p.KH <= 64 && p.nk == p.KH * p.KW) return launch_attn2_impl<T, HD, 2, 1>(p, stream);
+    if (p.KH + p.KW <= 32) return launch_attn2_impl<T, HD, 1, 1>(p, stream);
+    if (p.KH + p.KW <= 64) return launch_attn2_impl<T, HD, 1, 2>(p, stream);
+    return -1;   // caller falls back to the table-based v1 path
+}
+
+}  // namespace
+
+// returns -1 if this geometry is not covered by the fused kernel
+template <typename T>
+int launch_attention2(const AttnParams& p, hipStream_t stream) {
+    switch (p.hd) {
+        case 64: return launch_attn2_hd<T, 64>(p, stream);
+        case 80: return launch_attn2_hd<T, 80>(p, stream);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+template int launch_attention2<half_t>(const AttnParams&, hipStream_t);
+template int launch_attention2<float>(const AttnParams&, hipStream_t);
+
+}  // namespace cva

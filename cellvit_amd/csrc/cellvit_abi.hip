@@ -2,6 +2,7 @@
 // (cv_forward).  Host code only — the kernels live in gemm.hip / attention.hip / elementwise.hip.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -369,17 +370,27 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
         CVA_LAUNCH(launch_pad_kv<T>(pk, st));
     }
     const int KH = window ? ws : gh, KW = window ? ws : gw;
+    AttnParams a{};
+    a.Q = Q; a.K = K; a.Vt = Vt; a.out = attn_out;
+    a.S = S; a.heads = heads; a.L = L; a.Lp = Lp; a.hd = hd; a.D = D; a.nk = L; a.KH = KH; a.KW = KW;
+    a.scale = 1.0f / std::sqrt((float)hd);
+    a.ntok = ntok; a.win = window ? ws : 0; a.gw = gw; a.gh = gh; a.nwx = nwx; a.nwy = nwy;
+    static const int attn_variant = [] { const char* e = getenv("CVA_ATTN"); return e ? atoi(e) : 2; }();
+    if (attn_variant != 1) {
+        a.tab_h = tab_h; a.tab_w = tab_w;
+        ProfScope ps(KC_ATTN, 4.0 * (double)B * P * (window ? L : ntok) * hd * heads + (window ? 0.0 : 4.0 * B * has_cls * (double)ntok * hd * heads), st);
+        const int rc2 = launch_attention2<T>(a, st);
+        if (rc2 == 0) return CV_OK;
+        if (rc2 != -1) { cva_set_error("attention2 launch failed (%d)", rc2); return CV_ERR_HIP; }
+    }
+    a.tab_h = a.tab_w = nullptr;
     if (tab_h) {
         RelPosParams rp{};
         rp.Q = Q; rp.tab_h = tab_h; rp.tab_w = tab_w; rp.relh = relh; rp.relw = relw;
         rp.SH = S * heads; rp.L = L; rp.hd = hd; rp.KH = KH; rp.KW = KW;
         CVA_LAUNCH(launch_relpos<T>(rp, st));
     }
-    AttnParams a{};
-    a.Q = Q; a.K = K; a.Vt = Vt; a.relh = tab_h ? relh : nullptr; a.relw = tab_h ? relw : nullptr; a.out = attn_out;
-    a.S = S; a.heads = heads; a.L = L; a.Lp = Lp; a.hd = hd; a.D = D; a.nk = L; a.KH = KH; a.KW = KW;
-    a.scale = 1.0f / std::sqrt((float)hd);
-    a.ntok = ntok; a.win = window ? ws : 0; a.gw = gw; a.gh = gh; a.nwx = nwx; a.nwy = nwy;
+    a.relh = tab_h ? relh : nullptr; a.relw = tab_h ? relw : nullptr;
     { ProfScope ps(KC_ATTN, 4.0 * (double)B * P * (window ? L : ntok) * hd * heads + (window ? 0.0 : 4.0 * B * has_cls * (double)ntok * hd * heads), st);
       CVA_LAUNCH(launch_attention<T>(a, st)); }
     return CV_OK;

@@ -179,6 +179,9 @@ def _attention_ref(x, Wqkv, bqkv, tab_h, tab_w, B, gh, gw, has_cls, heads, D, wi
     (1, 16, 16, 0, 16, 1280, 0, True),   # SAM-H global, hd 80
     (1, 16, 16, 0, 16, 1280, 14, True),  # SAM-H window, hd 80
     (1, 14, 14, 0, 16, 1280, 14, True),  # exact window fit (no padding)
+    (1, 32, 32, 0, 4, 320, 0, True),     # 512-px tile global block: KH+KW = 64 -> two one-hot bias k-steps
+    (1, 64, 64, 0, 4, 320, 0, True),     # 1024-px tile global block: key-tile-aligned bias path, 4096 keys
+    (2, 64, 64, 0, 4, 256, 14, True),    # 1024-px tile window blocks: 64 -> pad 70, 25 windows
 ])
 def test_attention(dtype, B, gh, gw, has_cls, heads, D, win, rel):
     L, lib = _lib()
