@@ -41,6 +41,8 @@ struct GemmParams {
     int D, hd, heads, ntok, L, Lp;   // ntok tokens per image (incl. cls for ViT)
     int win, gw, gh, nwx, nwy;       // win > 0: window partition of the gh x gw token grid
     const void* zero;                // >= 16 B of zeros in device memory (filled in by launch_gemm)
+    int epi_vec;                     // 1: LDS-staged 16-byte epilogue stores (set by launch_gemm)
+    int dbg;                         // experiment switches (CVA_GEMM_DBG): 1 no staging, 2 no LDS reads, 4 no L2 prefetch
 };
 
 template <typename T> int launch_gemm(const GemmParams& p, int a_mode, hipStream_t stream);

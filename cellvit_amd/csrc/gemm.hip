@@ -16,14 +16,23 @@ namespace {
 constexpr int BM = 128, BN = 128, NT = 256;
 
 // C fragment layout: lane l, reg r -> row (l>>4)*4 + r, col l&15.  rowb/colb: this lane's first row / col.
-template <typename T, int OMODE>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], const int rowb, const int colb) {
+template <typename T, int OMODE, int MI = 4, int NJ = 4>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NJ], const int rowb, const int colb) {
     using TR = Traits<T>;
     T* outT = reinterpret_cast<T*>(p.out);
     float* outF = reinterpret_cast<float*>(p.out);
+    if (p.dbg & 8) {   // experiment: keep the accumulators live, store one value per lane
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (rowb < p.M && colb < p.N) { if (p.out_f32) outF[(long)rowb * p.ldc + colb] = t; else outT[(long)rowb * p.ldc + colb] = TR::from_float(t); }
+        return;
+    }
 
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int n = colb + j * 16;
         if (n >= p.N) continue;
         const float bv = p.bias ? p.bias[n] : 0.f;
@@ -42,7 +51,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             col_term = ((long)dy * (2 * p.Wd) + dx) * cout + co;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = rowb + i * 16 + r;
@@ -84,6 +93,152 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged epilogue: the 16x16 C fragments hold one column per lane, so direct stores are 2/4-byte
+// scatters (one store instruction per element — store-ISSUE bound, 25-40 % of a whole GEMM).  Each wave
+// transposes one 16-row slab at a time through a private LDS patch and writes 16-byte row segments.
+//   st: per-wave staging area of 16 x (NJ*16 + 4) floats.  Preconditions (checked on the host, p.epi_vec):
+//   N % 8 == 0 and 16-byte aligned destinations; see launch_gemm.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int OMODE, int MI, int NJ>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[MI][NJ], const int row0, const int col0,
+                                                  float* __restrict__ st, const int lane) {
+    using TR = Traits<T>;
+    constexpr int WN = NJ * 16, SP = WN + 4;
+    const int g = lane >> 4, li = lane & 15;
+    float bv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int n = col0 + j * 16 + li; bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f; }
+    T* outT = reinterpret_cast<T*>(p.out);
+    float* outF = reinterpret_cast<float*>(p.out);
+
+    // OUT_QKV: a 64-column wave slab lies inside one of q / k / v (D % 64 == 0)
+    int which = 0;
+    if (OMODE == OUT_QKV) which = col0 / p.D;
+    const bool vt_slab = OMODE == OUT_QKV && which == 2;
+
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] + bv[j];
+                if (p.act == ACT_GELU) v = gelu_erf(v);
+                else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                st[(g * 4 + r) * SP + j * 16 + li] = v;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int mrow = row0 + i * 16;
+        if (vt_slab) {
+            // V^T [S*heads, hd, Lp]: contiguous along the token axis -> read the slab column-wise
+            const int n = col0 + lane;            // WN == 64: one column per lane
+            if (n < p.N) {
+                const int c = n - 2 * p.D;
+                const int h = c / p.hd, d = c - h * p.hd;
+                T* vt = reinterpret_cast<T*>(p.vt_out);
+                const bool fast = p.win == 0 && (mrow + 15) < p.M && (mrow / p.ntok) == ((mrow + 15) / p.ntok) &&
+                                  ((mrow % p.ntok) & 7) == 0;
+                if (fast) {
+                    const int b = mrow / p.ntok, t0 = mrow - b * p.ntok;
+                    T* dst = vt + (((long)b * p.heads + h) * p.hd + d) * p.Lp + t0;
+                    Piece pk[2 * sizeof(T) / 2];   // 16 elements: 2 pieces (fp16) or 4 pieces (fp32)
+                    T* e = reinterpret_cast<T*>(pk);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e[r] = TR::from_float(st[r * SP + lane]);
+#pragma unroll
+                    for (int q = 0; q < (int)(2 * sizeof(T) / 2); ++q) store_piece(dst + q * (16 / (int)sizeof(T)), pk[q]);
+                } else {
+#pragma unroll 1
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mrow + r;
+                        if (m >= p.M) break;
+                        const int b = m / p.ntok, t = m - b * p.ntok;
+                        int s_ = b, pos = t;
+                        if (p.win > 0) {
+                            const int gy = t / p.gw, gx = t - gy * p.gw;
+                            const int wy = gy / p.win, wx = gx / p.win;
+                            s_ = (b * p.nwy + wy) * p.nwx + wx;
+                            pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
+                        }
+                        vt[(((long)s_ * p.heads + h) * p.hd + d) * p.Lp + pos] = TR::from_float(st[r * SP + lane]);
+                    }
+                }
+            }
+        } else {
+            const bool f32out = (OMODE == OUT_LINEAR) && p.out_f32;
+            // 8 elements per lane (T out: one 16-B store) or 4 (fp32 out: one 16-B store)
+            const int epl = f32out ? 4 : 8;
+            const int lpr = WN / epl;                 // lanes per row
+            const int rpp = 64 / lpr;                 // rows per pass
+            for (int rr = lane / lpr; rr < 16; rr += rpp) {
+                const int cc = (lane - (lane / lpr) * lpr) * epl;
+                const int m = mrow + rr, n = col0 + cc;
+                if (m >= p.M || n >= p.N) continue;
+                float v[8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(st + rr * SP + cc);
+                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+                if (!f32out) {
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(st + rr * SP + cc + 4);
+                    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+                }
+                long o;
+                if (OMODE == OUT_LINEAR) {
+                    long orow = m;
+                    if (p.o_rpi > 0) orow = (long)m + (long)(m / p.o_rpi) * p.o_extra + p.o_off;
+                    if (p.res) {
+                        const long rrow = p.res_mod > 0 ? (long)(m % p.res_mod) : orow;
+                        const float* rp = p.res + rrow * p.ldres + n;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp);
+                        v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
+                        if (!f32out) {
+                            const f32x4 r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+                            v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
+                        }
+                    }
+                    o = orow * (long)p.ldc + n;
+                    if (f32out) { f32x4 w = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(outF + o) = w; continue; }
+                } else if (OMODE == OUT_CONVT) {
+                    const int cout = p.N >> 2;
+                    const int dd = n / cout, co = n - dd * cout;
+                    const int hw = p.H * p.Wd;
+                    const int b = m / hw, r2 = m - b * hw;
+                    const int y = r2 / p.Wd, x = r2 - y * p.Wd;
+                    o = (((long)b * 2 * p.H + 2 * y + (dd >> 1)) * (2 * p.Wd) + 2 * x + (dd & 1)) * cout + co;
+                } else {   // OUT_QKV, q or k slab
+                    const int c = n - which * p.D;
+                    const int h = c / p.hd, d = c - h * p.hd;
+                    const int b = m / p.ntok, t = m - b * p.ntok;
+                    int s_ = b, pos = t;
+                    if (p.win > 0) {
+                        const int gy = t / p.gw, gx = t - gy * p.gw;
+                        const int wy = gy / p.win, wx = gx / p.win;
+                        s_ = (b * p.nwy + wy) * p.nwx + wx;
+                        pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
+                    }
+                    outT = reinterpret_cast<T*>(which == 0 ? p.q_out : p.k_out);
+                    o = (((long)s_ * p.heads + h) * p.L + pos) * p.hd + d;
+                }
+                // T output: 8 elements
+                if constexpr (sizeof(T) == 2) {
+                    Piece pk; T* e = reinterpret_cast<T*>(&pk);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) e[q] = TR::from_float(v[q]);
+                    store_piece(outT + o, pk);
+                } else {
+                    f32x4 w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(outT + o) = w0;
+                    *reinterpret_cast<f32x4*>(outT + o + 4) = w1;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 
 template <typename T, int AMODE, int OMODE>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
@@ -200,7 +355,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    gemm_epilogue<T, OMODE>(p, acc, m0 + wm * 64 + (lane >> 4) * 4, n0 + wn * 64 + (lane & 15));
+    if (p.epi_vec) {
+        float* st = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+        gemm_epilogue_lds<T, OMODE, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, st, lane);
+    } else {
+        gemm_epilogue<T, OMODE>(p, acc, m0 + wm * 64 + (lane >> 4) * 4, n0 + wn * 64 + (lane & 15));
+    }
 }
 
 
@@ -215,24 +375,39 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
 // one 128-B line: global coalescing is unchanged.  Out-of-range rows / K tail read a zero page.
 // One barrier per K tile; the next tile's DMA is in flight while the current one is multiplied.
 // ================================================================================================
-template <typename T, int AMODE, int OMODE, int WM>
-__global__ __launch_bounds__(WM * 128, 1) void gemm_glds_kernel(const GemmParams p) {
+// grouped rasterisation: consecutive ids walk GM tile rows of one tile column before moving to the next
+// column, so the blocks resident on one XCD at a time share few distinct A and W panels (L2 hits).
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int group = id / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(GM, tiles_m - first_m);
+    const int within = id - group * per_group;
+    tm = first_m + within % gsz;
+    tn = within / gsz;
+}
+
+template <typename T, int AMODE, int OMODE, int WMW, int WNW, int MI, int NJ>
+__global__ __launch_bounds__(WMW * WNW * 64) void gemm_glds_kernel(const GemmParams p) {
     using TR = Traits<T>;
     constexpr int BK = TR::BK, PE = TR::PIECE;
-    constexpr int TBM = WM * 64, TBN = 128, NTH = WM * 128, NW = NTH / 64;
+    constexpr int TBM = WMW * MI * 16, TBN = WNW * NJ * 16, NTH = WMW * WNW * 64, NW = NTH / 64;
     constexpr int ROWB = 128;                         // bytes per tile row
     constexpr int A_CHUNKS = TBM / 8, B_CHUNKS = TBN / 8;   // 1-KiB chunks (8 rows each)
     constexpr int A_PER_WAVE = A_CHUNKS / NW, B_PER_WAVE = B_CHUNKS / NW;
+    static_assert(A_CHUNKS % NW == 0 && B_CHUNKS % NW == 0, "tile rows must split evenly over the waves");
     constexpr int KSTEPS = BK / 32;
     constexpr int BUF_BYTES = (TBM + TBN) * ROWB;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNW, wn = wave - wm * WNW;
     const int tiles_n = (p.N + TBN - 1) / TBN, tiles_m = (p.M + TBM - 1) / TBM;
-    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (bid / tiles_n) * TBM, n0 = (bid % tiles_n) * TBN;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * TBN;
 
     const T* __restrict__ Ap = reinterpret_cast<const T*>(p.A);
     const T* __restrict__ A2p = reinterpret_cast<const T*>(p.A2);
@@ -309,17 +484,15 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_glds_kernel(const GemmParams
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4)(0.f);
 
     // fragment read addressing: row r, logical piece lp -> byte r*128 + ((lp ^ ((r>>1)&7)) << 4)
     const int g = lane >> 4;
-    int a_row[4], b_row[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { a_row[i] = wm * 64 + i * 16 + (lane & 15); b_row[i] = wn * 64 + i * 16 + (lane & 15); }
+    const int a_row0 = wm * (MI * 16) + (lane & 15), b_row0 = wn * (NJ * 16) + (lane & 15);
 
     auto load_frag = [&](const unsigned char* base, int row, int ks) -> typename TR::Frag {
         const int sw = (row >> 1) & 7;
@@ -337,31 +510,72 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_glds_kernel(const GemmParams
         }
     };
 
+    // ---- L2 prefetch: one 4-byte load per thread touches every 128-B line of tile kt+2 (A rows then W rows),
+    // issued AFTER the DMA of tile kt+1 and left in flight across the barrier (counted vmcnt).  The DMA of the
+    // following iteration then hits L2, so the per-iteration wait is an L2 round trip instead of an HBM/MALL one.
+    constexpr bool L2PF = (AMODE == A_LINEAR) && (TBM + TBN) == NTH;    // exactly one line per thread
+    unsigned pf_dummy = 0;
+    const T* pf_row = Zp;
+    bool pf_ok = false;
+    if (L2PF) {
+        if (tid < TBM) {
+            const int m = m0 + tid;
+            if (m < p.M) {
+                long r = m;
+                if (p.a_rpi > 0) r = (long)m + (long)(m / p.a_rpi) * p.a_extra + p.a_off;
+                pf_row = Ap + r * (long)p.lda; pf_ok = true;
+            }
+        } else {
+            const int n = n0 + (tid - TBM);
+            if (n < p.N) { pf_row = Wp + (long)n * p.ldw; pf_ok = true; }
+        }
+    }
+
     const int nk = (p.K + BK - 1) / BK;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        if (kt + 1 < nk && !(p.dbg & 1)) stage(kt + 1, buf ^ 1);
+        const bool do_pf = L2PF && (kt + 2 < nk) && !(p.dbg & 4);          // block-uniform
+        if (do_pf) {
+            const T* src = pf_ok ? pf_row + (long)(kt + 2) * BK : Zp;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_dummy) : "v"(src) : "memory");
+        }
         const unsigned char* sA = smem_raw + buf * BUF_BYTES;
         const unsigned char* sB = sA + TBM * ROWB;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            typename TR::Frag a[4], b[4];
+            typename TR::Frag b[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = load_frag(sA, a_row[i], ks);
+            for (int j = 0; j < NJ; ++j) b[j] = load_frag(sB, b_row0 + j * 16, ks);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = load_frag(sB, b_row[j], ks);
+            for (int i = 0; i < MI; ++i) {
+                const typename TR::Frag a = load_frag(sA, a_row0 + i * 16, ks);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) TR::mma(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) TR::mma(a, b[j], acc[i][j]);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (L2PF) {
+            // tile kt+1 has landed (all older VMEM ops retire in order); the prefetch may stay in flight
+            if (do_pf) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
-    gemm_epilogue<T, OMODE>(p, acc, m0 + wm * 64 + (lane >> 4) * 4, n0 + wn * 64 + (lane & 15));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy) :: "memory");
+    if (p.epi_vec && NJ == 4) {
+        float* st = reinterpret_cast<float*>(smem_raw) + wave * (16 * 68);
+        gemm_epilogue_lds<T, OMODE, MI, NJ>(p, acc, m0 + wm * (MI * 16), n0 + wn * (NJ * 16), st, lane);
+    } else {
+        gemm_epilogue<T, OMODE, MI, NJ>(p, acc, m0 + wm * (MI * 16) + (lane >> 4) * 4, n0 + wn * (NJ * 16) + (lane & 15));
+    }
 }
 
 }  // namespace
@@ -372,41 +586,58 @@ void* zero_page() {   // 256 B of zeros: the DMA source of out-of-range pieces
     if (!z) { if (hipMalloc(&z, 256) != hipSuccess) return nullptr; (void)hipMemset(z, 0, 256); }
     return z;
 }
-int gemm_variant() {   // CVA_GEMM=1: register-staged v1; 2 (default): 128x128 glds; 3: 256x128 glds
+int gemm_variant() {   // CVA_GEMM=1 (default): register-staged 128x128; 2: glds 128x128; 3: glds 256x128; 4: glds 256x256
     static int v = -1;
-    if (v < 0) { const char* e = getenv("CVA_GEMM"); v = e ? atoi(e) : 2; if (v < 1 || v > 3) v = 2; }
+    if (v < 0) { const char* e = getenv("CVA_GEMM"); v = e ? atoi(e) : 1; if (v < 1 || v > 4) v = 1; }
     return v;
 }
-template <typename T, int AMODE, int OMODE, int WM>
+template <typename T, int AMODE, int OMODE, int WMW, int WNW, int MI, int NJ>
 int launch_glds(const GemmParams& p, hipStream_t stream) {
-    constexpr int TBM = WM * 64, TBN = 128;
+    constexpr int TBM = WMW * MI * 16, TBN = WNW * NJ * 16;
     const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
     const size_t lds = 2 * (size_t)(TBM + TBN) * 128;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AMODE, OMODE, WM>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AMODE, OMODE, WMW, WNW, MI, NJ>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return (int)hipGetLastError();
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<T, AMODE, OMODE, WM>), dim3(tiles), dim3(WM * 128), lds, stream, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, AMODE, OMODE, WMW, WNW, MI, NJ>), dim3(tiles), dim3(WMW * WNW * 64), lds, stream, p);
     return (int)hipGetLastError();
 }
-template <typename T, int WM>
+template <typename T, int WMW, int WNW, int MI, int NJ>
 int dispatch_glds(const GemmParams& p, int a_mode, hipStream_t stream) {
     if (a_mode == A_CONV3) {
         if (p.out_mode != OUT_LINEAR) return (int)hipErrorInvalidValue;
-        return launch_glds<T, A_CONV3, OUT_LINEAR, WM>(p, stream);
+        return launch_glds<T, A_CONV3, OUT_LINEAR, WMW, WNW, MI, NJ>(p, stream);
     }
-    if (p.out_mode == OUT_LINEAR) return launch_glds<T, A_LINEAR, OUT_LINEAR, WM>(p, stream);
-    if (p.out_mode == OUT_QKV) return launch_glds<T, A_LINEAR, OUT_QKV, WM>(p, stream);
-    return launch_glds<T, A_LINEAR, OUT_CONVT, WM>(p, stream);
+    if (p.out_mode == OUT_LINEAR) return launch_glds<T, A_LINEAR, OUT_LINEAR, WMW, WNW, MI, NJ>(p, stream);
+    if (p.out_mode == OUT_QKV) return launch_glds<T, A_LINEAR, OUT_QKV, WMW, WNW, MI, NJ>(p, stream);
+    return launch_glds<T, A_LINEAR, OUT_CONVT, WMW, WNW, MI, NJ>(p, stream);
 }
 }  // namespace
 
 template <typename T>
 int launch_gemm(const GemmParams& p_in, int a_mode, hipStream_t stream) {
     GemmParams p = p_in;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CVA_GEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     if (((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) <= 0) return 0;
+    {   // vectorised (LDS-staged) epilogue preconditions
+        static int epi = -1;
+        if (epi < 0) { const char* e = getenv("CVA_EPI"); epi = e ? atoi(e) : 1; }
+        const size_t es = sizeof(T);
+        bool ok = epi != 0 && p.N % 8 == 0;
+        auto al16 = [](const void* q) { return ((size_t)q & 15) == 0; };
+        if (p.out_mode == OUT_LINEAR) {
+            ok = ok && al16(p.out) && ((size_t)p.ldc * (p.out_f32 ? 4 : es)) % 16 == 0;
+            if (p.res) ok = ok && al16(p.res) && p.ldres % 4 == 0;
+        } else if (p.out_mode == OUT_QKV) {
+            ok = ok && p.hd % 8 == 0 && p.D % 64 == 0 && al16(p.q_out) && al16(p.k_out) && al16(p.vt_out) && p.Lp % 8 == 0;
+        } else {
+            ok = ok && (p.N / 4) % 8 == 0 && al16(p.out);
+        }
+        p.epi_vec = ok ? 1 : 0;
+    }
     const int variant = gemm_variant();
     if (variant >= 2) {
         p.zero = zero_page();
@@ -414,10 +645,13 @@ int launch_gemm(const GemmParams& p_in, int a_mode, hipStream_t stream) {
         // DMA pieces are whole 16-B units: the linear A operand needs 16-B aligned rows
         const bool aligned = a_mode == A_CONV3 || ((size_t)p.lda * sizeof(T)) % 16 == 0;
         if (aligned) {
-            // 256-row tiles only pay when the grid still fills the chip
-            const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
-            if (variant == 3 && tiles256 >= 512) return dispatch_glds<T, 4>(p, a_mode, stream);
-            return dispatch_glds<T, 2>(p, a_mode, stream);
+            // big tiles only pay when the grid still fills the chip (256 CUs) about twice over
+            const long t256x256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+            const long t256x128 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+            if (variant == 4 && p.N >= 256 && t256x256 >= 256) return dispatch_glds<T, 2, 4, 8, 4>(p, a_mode, stream);
+            if (variant >= 3 && p.N <= 64 && (p.M + 255) / 256 >= 512) return dispatch_glds<T, 4, 1, 4, 4>(p, a_mode, stream);
+            if (variant >= 3 && t256x128 >= 512) return dispatch_glds<T, 4, 2, 4, 4>(p, a_mode, stream);
+            if (variant == 2) return dispatch_glds<T, 2, 2, 4, 4>(p, a_mode, stream);
         }
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);

@@ -1,0 +1,42 @@
+"""Micro-benchmark of the linear GEMM entry point (A/B of kernel variants via CVA_GEMM).
+    CVA_GEMM=4 python tools/bench_gemm.py [M N K] [iters]
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from cellvit_amd import _lib  # noqa: E402
+
+
+def main():
+    M, N, K = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (16384, 5120, 1280)
+    iters = int(sys.argv[4]) if len(sys.argv) >= 5 else 20
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    A = (torch.rand(M, K, device="cuda", generator=g) * 2 - 1).half()
+    W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / K ** 0.5).half()
+    b = torch.zeros(N, device="cuda")
+    out = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for _ in range(3):
+        _lib.check(lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, 0, None))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, 0, None)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    ref = (A[:256].float() @ W.float().t())
+    err = float((out[:256].float() - ref).abs().max())
+    print(f"CVA_GEMM={os.environ.get('CVA_GEMM', '1')} M={M} N={N} K={K}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s  maxerr {err:.3e}")
+
+
+if __name__ == "__main__":
+    main()
