@@ -423,7 +423,8 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
     __shared__ int s_lab[POOL_LDS];
     const int lane = threadIdx.x;
     const int N = p.H * p.W, W = p.W, H = p.H;
-    for (int tile = 0; tile < p.B; ++tile) {
+    {
+        const int tile = blockIdx.y;
         const long base = (long)tile * N;
         const double* dist = p.dist + base;
         const uint8_t* blb = p.blb + base;
@@ -825,7 +826,7 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     fp.comp_list = w->comp_list; fp.comp_count = comp_count; fp.list_cap = w->list_cap; fp.queue_head = queue_head;
     fp.ovf_v = w->ovf_v; fp.ovf_age = w->ovf_age; fp.ovf_idx = w->ovf_idx; fp.ovf_lab = w->ovf_lab; fp.ovf_cursor = w->ovf_cursor;
     fp.H = H; fp.W = W; fp.B = B;
-    hipLaunchKernelGGL(k_flood, dim3(2048), dim3(64), 0, st, fp);
+    hipLaunchKernelGGL(k_flood, dim3(1024, B), dim3(64), 0, st, fp);
     // ---- P7/P8: per-instance records + contours ----
     CVA_MS(w->st.cnt, 0, S * 4); CVA_MS(w->st.sx, 0, S * 8); CVA_MS(w->st.sy, 0, S * 8);
     CVA_MS(w->st.rmin, 0x7f, S * 4); CVA_MS(w->st.cmin, 0x7f, S * 4); CVA_MS(w->st.first, 0x7f, S * 4);
