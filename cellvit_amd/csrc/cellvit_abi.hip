@@ -916,7 +916,7 @@ extern "C" int cv_pp_create(int max_batch, int H, int W, int max_inst, int max_p
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { cva_set_error("no HIP device visible (no CPU fallback)"); return CV_ERR_HIP; }
     cv_pp* p = new cv_pp();
     p->d.B = max_batch; p->d.H = H; p->d.W = W; p->d.max_inst = max_inst; p->d.max_pts = max_pts;
-    p->d.max_ids = std::max(64, H * W / 8);
+    p->d.max_ids = std::max(64, H * W / 16);   // every opened marker component covers >= one 5x5 ellipse (17 px)
     if (pp_workspace_create(p->d, &p->ws) != 0) { delete p; cva_set_error("postproc workspace allocation failed"); return CV_ERR_HIP; }
     *out = p;
     return CV_OK;

@@ -65,6 +65,38 @@ __global__ void k_cc_merge(int* __restrict__ Lb, int H, int W) {
     }
 }
 
+// Fast path for W % 64 == 0 (a wave = 64 consecutive pixels of one row): horizontal runs are linked
+// without atomics (every foreground pixel points at the first pixel of its run inside the 64-pixel chunk),
+// and only the first pixel of every vertical overlap segment / chunk seam does a union.
+__global__ void k_cc_init_runs(const uint8_t* __restrict__ src, int invert, int* __restrict__ L, int N) {
+    const long base = (long)blockIdx.y * N;
+    const int lane = threadIdx.x & 63;
+    for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < N; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + lane;
+        const bool fg = (src[base + i] != 0) != (invert != 0);
+        const unsigned long long m = __ballot(fg);
+        int v = -1;
+        if (fg) {
+            const unsigned long long zeros_below = ~m & ((1ull << lane) - 1ull);
+            const int start = zeros_below ? 64 - __clzll(zeros_below) : 0;
+            v = i0 + start;
+        }
+        L[base + i] = v;
+    }
+}
+
+__global__ void k_cc_merge_runs(int* __restrict__ Lb, int H, int W) {
+    const int N = H * W;
+    int* L = Lb + (long)blockIdx.y * N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        if (L[i] < 0) continue;
+        const int y = i / W, x = i - y * W;
+        const bool left = x > 0 && L[i - 1] >= 0;
+        if (left && (x & 63) == 0) uf_union(L, i, i - 1);                    // run continues across a chunk seam
+        if (y > 0 && L[i - W] >= 0 && !(left && L[i - W - 1] >= 0)) uf_union(L, i, i - W);
+    }
+}
+
 __global__ void k_cc_flatten(int* __restrict__ Lb, int N) {
     int* L = Lb + (long)blockIdx.y * N;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
@@ -82,8 +114,11 @@ __global__ void k_comp_stats(const int* __restrict__ Lb, int* __restrict__ csize
         const int r = L[i];
         if (r < 0) continue;
         const int y = i / W, x = i - y * W;
-        atomicAdd(&cs[r], 1);
-        atomicMin(&y0[r], y); atomicMax(&y1[r], y); atomicMin(&x0[r], x); atomicMax(&x1[r], x);
+        if (x > 0 && L[i - 1] >= 0) continue;          // one thread per horizontal run
+        int len = 1;
+        while (x + len < W && L[i + len] >= 0) ++len;
+        atomicAdd(&cs[r], len);
+        atomicMin(&y0[r], y); atomicMax(&y1[r], y); atomicMin(&x0[r], x); atomicMax(&x1[r], x + len - 1);
     }
 }
 
@@ -341,12 +376,14 @@ __global__ void k_scan_partial(const int* __restrict__ Lb, int N, int* __restric
     if (threadIdx.x == 0) bsum[(long)blockIdx.y * nblk + blockIdx.x] = tot;
 }
 
-__global__ void k_scan_blocks(int* __restrict__ bsum, int nblk) {   // one block per tile, nblk <= NT*8
+__global__ void k_scan_blocks(int* __restrict__ bsum, int nblk, int* __restrict__ total_out) {   // one block per tile, nblk <= NT*8
     int* b = bsum + (long)blockIdx.x * nblk;
     int v[8], c = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const int i = threadIdx.x * 8 + j; v[j] = i < nblk ? b[i] : 0; c += v[j]; }
-    int run = block_exclusive_scan(c, nullptr);
+    int tot;
+    int run = block_exclusive_scan(c, &tot);
+    if (threadIdx.x == 0) total_out[blockIdx.x] = tot;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const int i = threadIdx.x * 8 + j; if (i < nblk) b[i] = run; run += v[j]; }
 }
@@ -555,29 +592,42 @@ __global__ void k_inst_stats(const int* __restrict__ inst, const uint8_t* __rest
         if (id <= 0) { zero_seen = true; continue; }
         if (id > max_ids) continue;
         const int y = i / W, x = i - y * W;
-        atomicAdd(&st.cnt[sb + id], 1);
-        atomicAdd(&st.sx[sb + id], (unsigned long long)x);
-        atomicAdd(&st.sy[sb + id], (unsigned long long)y);
+        if (x > 0 && inst[base + i - 1] == id) continue;     // one thread per horizontal run of the instance
+        int len = 0;
+        unsigned h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        do {
+            if (nr_types > 0) {
+                int t = type[base + i + len]; if (t > 7) t = 7;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) h[k] += (t == k);
+            }
+            ++len;
+        } while (x + len < W && inst[base + i + len] == id);
+        atomicAdd(&st.cnt[sb + id], len);
+        atomicAdd(&st.sx[sb + id], (unsigned long long)len * x + (unsigned long long)len * (len - 1) / 2);
+        atomicAdd(&st.sy[sb + id], (unsigned long long)len * y);
         atomicMin(&st.rmin[sb + id], y); atomicMax(&st.rmax[sb + id], y);
-        atomicMin(&st.cmin[sb + id], x); atomicMax(&st.cmax[sb + id], x);
+        atomicMin(&st.cmin[sb + id], x); atomicMax(&st.cmax[sb + id], x + len - 1);
         atomicMin(&st.first[sb + id], i);
-        if (nr_types > 0) { int t = type[base + i]; if (t > 7) t = 7; atomicAdd(&st.hist[(sb + id) * 8 + t], 1u); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (h[k]) atomicAdd(&st.hist[(sb + id) * 8 + k], h[k]);
     }
     if (__any(zero_seen) && (threadIdx.x & 63) == 0) st.has_zero[tile] = 1;
 }
 
 // one block per tile: ascending-id compaction (== np.unique order) + record arithmetic
 __global__ void k_inst_records(StatArrays st, InstanceRec* __restrict__ recs, int* __restrict__ n_recs, int max_ids,
-                               int max_inst, int nr_types) {
+                               int max_inst, int nr_types, const int* __restrict__ nmark) {
     const int tile = blockIdx.x;
     const long sb = (long)tile * (max_ids + 1);
     __shared__ int s_base;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
     const bool drop_first = st.has_zero[tile] == 0;   // np.unique(pred_inst)[1:] drops the smallest VALUE (quirk 1)
-    for (int c0 = 1; c0 <= max_ids; c0 += NT) {
+    const int id_hi = min(max_ids, nmark[tile]);      // ids are ranks of marker components
+    for (int c0 = 1; c0 <= id_hi; c0 += NT) {
         const int id = c0 + threadIdx.x;
-        const bool live = id <= max_ids && st.cnt[sb + id] > 0;
+        const bool live = id <= id_hi && st.cnt[sb + id] > 0;
         int tot;
         const int pos = block_exclusive_scan(live ? 1 : 0, &tot) + s_base;
         __syncthreads();
@@ -782,9 +832,18 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     CVA_MS(w->bb, 0x7f, (size_t)B * N * 16);            // y0 / x0 = large positive for atomicMin
     CVA_MS(w->counters, 0, (size_t)B * 16);
     CVA_MS(w->ovf_cursor, 0, (size_t)B * 8);
-    hipLaunchKernelGGL(k_cc_init, grid, blk, 0, st, bin, 0, w->L1, N);
-    hipLaunchKernelGGL(k_cc_merge, grid, blk, 0, st, w->L1, H, W);
-    hipLaunchKernelGGL(k_cc_flatten, grid, blk, 0, st, w->L1, N);
+    const bool runs = (W % 64) == 0;
+    auto cc = [&](const uint8_t* src, int invert, int* L) {
+        if (runs) {
+            hipLaunchKernelGGL(k_cc_init_runs, grid, blk, 0, st, src, invert, L, N);
+            hipLaunchKernelGGL(k_cc_merge_runs, grid, blk, 0, st, L, H, W);
+        } else {
+            hipLaunchKernelGGL(k_cc_init, grid, blk, 0, st, src, invert, L, N);
+            hipLaunchKernelGGL(k_cc_merge, grid, blk, 0, st, L, H, W);
+        }
+        hipLaunchKernelGGL(k_cc_flatten, grid, blk, 0, st, L, N);
+    };
+    cc(bin, 0, w->L1);
     // y1 / x1 planes must start at -1 for atomicMax: overwrite those two planes
     for (int b = 0; b < B; ++b) CVA_MS(w->bb + ((size_t)b * 4 + 1) * N, 0xff, (size_t)N * 4);
     for (int b = 0; b < B; ++b) CVA_MS(w->bb + ((size_t)b * 4 + 3) * N, 0xff, (size_t)N * 4);
@@ -803,19 +862,16 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     hipLaunchKernelGGL(k_combine, grid, blk, 0, st, w->sob, w->params_sob, w->blb, w->d0, w->mk, N);
     hipLaunchKernelGGL(k_blur_neg, grid, blk, 0, st, w->d0, w->dist, H, W);
     // ---- P5: fill holes (background components not touching the border), open, label, size filter ----
-    hipLaunchKernelGGL(k_cc_init, grid, blk, 0, st, w->mk, 1, w->L2, N);
-    hipLaunchKernelGGL(k_cc_merge, grid, blk, 0, st, w->L2, H, W);
-    hipLaunchKernelGGL(k_cc_flatten, grid, blk, 0, st, w->L2, N);
+    cc(w->mk, 1, w->L2);
     CVA_MS(w->flag, 0, (size_t)B * N * 4);
     hipLaunchKernelGGL(k_border_flag, dim3((2 * (H + W) + NT - 1) / NT, B), blk, 0, st, w->L2, w->flag, H, W);
     hipLaunchKernelGGL(k_fill, grid, blk, 0, st, w->mk, w->L2, w->flag, w->mk2, N);
     hipLaunchKernelGGL((k_morph5<true>), grid, blk, 0, st, w->mk2, w->mk, H, W);
     hipLaunchKernelGGL((k_morph5<false>), grid, blk, 0, st, w->mk, w->mk2, H, W);
-    hipLaunchKernelGGL(k_cc_init, grid, blk, 0, st, w->mk2, 0, w->L2, N);
-    hipLaunchKernelGGL(k_cc_merge, grid, blk, 0, st, w->L2, H, W);
-    hipLaunchKernelGGL(k_cc_flatten, grid, blk, 0, st, w->L2, N);
+    cc(w->mk2, 0, w->L2);
     hipLaunchKernelGGL(k_scan_partial, dim3(w->nblk, B), blk, 0, st, w->L2, N, w->bsum, w->nblk);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(B), blk, 0, st, w->bsum, w->nblk);
+    int* nmark = w->counters + 2 * B;         // [B]
+    hipLaunchKernelGGL(k_scan_blocks, dim3(B), blk, 0, st, w->bsum, w->nblk, nmark);
     hipLaunchKernelGGL(k_scan_apply, dim3(w->nblk, B), blk, 0, st, w->L2, N, w->bsum, w->nblk, w->rank);
     CVA_MS(w->msize, 0, S * 4);
     hipLaunchKernelGGL(k_marker_ids, grid, blk, 0, st, w->L2, w->rank, w->marker, w->msize, N, d.max_ids);
@@ -833,7 +889,7 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     CVA_MS(w->st.rmax, 0xff, S * 4); CVA_MS(w->st.cmax, 0xff, S * 4);
     CVA_MS(w->st.hist, 0, S * 32); CVA_MS(w->st.has_zero, 0, (size_t)B * 4);
     hipLaunchKernelGGL(k_inst_stats, grid, blk, 0, st, inst_out, type, w->st, H, W, d.max_ids, nr_types);
-    hipLaunchKernelGGL(k_inst_records, dim3(B), blk, 0, st, w->st, recs, n_recs, d.max_ids, d.max_inst, nr_types);
+    hipLaunchKernelGGL(k_inst_records, dim3(B), blk, 0, st, w->st, recs, n_recs, d.max_ids, d.max_inst, nr_types, nmark);
     const dim3 cgrid((d.max_inst + 63) / 64 > 64 ? 64 : (d.max_inst + 63) / 64, B);
     hipLaunchKernelGGL(k_contour_count, cgrid, dim3(64), 0, st, inst_out, recs, n_recs, H, W, d.max_inst);
     hipLaunchKernelGGL(k_contour_offsets, dim3(B), blk, 0, st, recs, n_recs, n_pts, d.max_inst);
