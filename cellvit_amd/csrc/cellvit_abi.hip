@@ -328,6 +328,15 @@ int run_conv3(const void* s1, int C1, const void* s2, int C2, const ConvW& w, vo
     p.bias = w.bias; p.act = w.relu ? ACT_RELU : ACT_NONE;
     p.out_mode = OUT_LINEAR; p.out_f32 = out_f32; p.out = out; p.ldc = w.Cout;
     ProfScope ps(KC_CONV3, 2.0 * p.M * (double)w.Cout * 9.0 * w.Cin_real, st);
+    if (sizeof(T) == 2) {   // fp16 production path: halo-tiled direct convolution where the layer fits it
+        static const int conv_variant = [] { const char* e = getenv("CVA_CONV"); return e ? atoi(e) : 2; }();
+        if (conv_variant != 1) {
+            p.zero = gemm_zero_page();
+            const int rch = launch_conv3x3_halo(p, B, st);
+            if (rch == 0) return CV_OK;
+            if (rch != -1) { cva_set_error("conv3x3 halo launch failed (%d)", rch); return CV_ERR_HIP; }
+        }
+    }
     const int rc = launch_gemm<T>(p, A_CONV3, st);
     if (rc) { cva_set_error("conv3x3 launch failed (%d)", rc); return CV_ERR_HIP; }
     return CV_OK;
@@ -912,6 +921,7 @@ static_assert(sizeof(cv_instance) == sizeof(InstanceRec), "cv_instance / Instanc
 
 extern "C" int cv_pp_create(int max_batch, int H, int W, int max_inst, int max_pts, cv_pp** out) {
     if (!out || max_batch <= 0 || H <= 0 || W <= 0 || max_inst <= 0 || max_pts < 0) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    if ((long)H * W > (1L << 20)) { cva_set_error("post-processing tiles are limited to 2^20 pixels (1024 x 1024): flood keys pack the pixel index in 20+ bits"); return CV_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { cva_set_error("no HIP device visible (no CPU fallback)"); return CV_ERR_HIP; }
     cv_pp* p = new cv_pp();

@@ -1,0 +1,211 @@
+// Halo-tiled direct 3x3 convolution on MFMA for gfx950 (fp16 production path of the U-Net decoder).
+//
+// Conv2d 3x3 p1 + folded bias/BatchNorm + ReLU on NHWC activations (reference: Conv2DBlock / Deconv2DBlock,
+// models/segmentation/cell_segmentation/utils.py:29-40, 73-83), optionally over the channel concat of two
+// sources (cellvit.py:236-242) which is never materialised.
+//
+// The implicit-GEMM formulation (gemm.hip, A_CONV3) re-fetches every input pixel nine times through L2.
+// Here a workgroup stages, per 32-channel chunk, the (16+2) x (32+2) input halo ONCE into LDS together with
+// the nine 64 x 32 filter taps, and the nine taps are then pure LDS -> MFMA work:
+//   staged bytes per chunk 76 KB for 18.9 MFLOP  ->  ~250 FLOP per staged byte (implicit GEMM: 64).
+// Staging is direct-to-LDS DMA (global_load_lds_dwordx4); a pixel / filter row is 64 bytes = 4 pieces and the
+// bank-conflict fix is the source-side XOR  piece ^= ((row >> 2) & 1) << 1  (conflict-free for ANY base pixel,
+// which matters because the nine taps read the halo at nine different alignments).
+// 512 threads = 8 waves; wave w owns image rows 2w, 2w+1 of the 16 x 32 pixel tile (64 pixels) x 64 output
+// channels = 4 x 4 fragments of v_mfma_f32_16x16x32_f16.  Epilogue: LDS transpose -> 16-byte NHWC stores.
+#include <stdlib.h>
+
+#include "common.h"
+#include "gemm.h"
+
+namespace cva {
+
+namespace {
+
+constexpr int TH = 16, TW = 32, HW_ = TW + 2, HH_ = TH + 2;
+constexpr int HALO_PIX = HH_ * HW_;                  // 612
+constexpr int HALO_INSTR = (HALO_PIX + 15) / 16;     // 39 one-KiB DMA instructions
+constexpr int HALO_BYTES = HALO_INSTR * 1024;        // 39936
+constexpr int W_INSTR = 9 * 4;                       // 9 taps x 64 rows / 16 rows per instruction
+constexpr int W_BYTES = W_INSTR * 1024;              // 36864
+constexpr int CONV_LDS = HALO_BYTES + W_BYTES;       // 76800 -> two workgroups per CU
+constexpr int NTH = 512, NWAVE = 8;
+constexpr int MAX_H = (HALO_INSTR + NWAVE - 1) / NWAVE;   // 5
+constexpr int MAX_W = (W_INSTR + NWAVE - 1) / NWAVE;      // 5
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
+
+template <int MINW>
+__global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParams p) {
+    using TR = Traits<half_t>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sH = smem;
+    unsigned char* sW = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = p.H, W = p.Wd;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; const int b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int n0 = blockIdx.y * 64;
+    const int ctot = p.C1 + p.C2;
+
+    const half_t* __restrict__ S1 = reinterpret_cast<const half_t*>(p.A);
+    const half_t* __restrict__ S2 = reinterpret_cast<const half_t*>(p.A2);
+    const half_t* __restrict__ Wp = reinterpret_cast<const half_t*>(p.W);
+    const half_t* __restrict__ Zp = reinterpret_cast<const half_t*>(p.zero);
+
+    // ---- per-lane staging descriptors (fixed over the channel loop) ----
+    int h_pix[MAX_H];   // pixel index * 4 + logical piece, or -1 (zero page)
+#pragma unroll
+    for (int i = 0; i < MAX_H; ++i) {
+        const int k = wave + NWAVE * i;                 // DMA instruction index
+        const int hp = k * 16 + (lane >> 2);            // halo pixel
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = k < HALO_INSTR && hp < HALO_PIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        h_pix[i] = ok ? ((((b * H + gy) * W + gx) << 2) | ((lane & 3) ^ swz(hp))) : -1;
+    }
+    int w_row[MAX_W];   // element offset of (row, tap) + logical piece * 8, or -1
+#pragma unroll
+    for (int i = 0; i < MAX_W; ++i) {
+        const int k = wave + NWAVE * i;
+        const int tap = k >> 2, n = (k & 3) * 16 + (lane >> 2);
+        const bool ok = k < W_INSTR && (n0 + n) < p.N;
+        w_row[i] = ok ? (n0 + n) * p.ldw + tap * ctot + ((lane & 3) ^ swz(n)) * 8 : -1;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+
+    // fragment addressing
+    int a_hp[4];                                     // halo pixel of (fragment i, lane) for the centre tap
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_hp[i] = (2 * wave + (i >> 1) + 1) * HW_ + ((i & 1) * 16 + li + 1);
+    int b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int n = j * 16 + li; b_off[j] = n * 64 + ((g ^ swz(n)) << 4); }
+
+    const int nchunks = ctot / 32;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * 32;
+        const bool second = c0 >= p.C1;
+        const half_t* __restrict__ src = second ? S2 : S1;
+        const int cs = second ? p.C2 : p.C1;
+        const int cc = second ? c0 - p.C1 : c0;
+        __syncthreads();                              // previous chunk fully consumed
+#pragma unroll
+        for (int i = 0; i < MAX_H; ++i) {
+            const int k = wave + NWAVE * i;
+            if (k < HALO_INSTR) {                     // wave-uniform
+                const half_t* s = h_pix[i] >= 0 ? src + (long)(h_pix[i] >> 2) * cs + cc + (h_pix[i] & 3) * 8 : Zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                                 (__attribute__((address_space(3))) void*)(sH + k * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAX_W; ++i) {
+            const int k = wave + NWAVE * i;
+            if (k < W_INSTR) {
+                const half_t* s = w_row[i] >= 0 ? Wp + w_row[i] + c0 : Zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                                 (__attribute__((address_space(3))) void*)(sW + k * 1024), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            TR::Frag bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = TR::load_frag(reinterpret_cast<const half_t*>(sW + tap * 4096 + b_off[j]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hp = a_hp[i] + dy * HW_ + dx;
+                const TR::Frag afr = TR::load_frag(reinterpret_cast<const half_t*>(sH + hp * 64 + ((g ^ swz(hp)) << 4)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) TR::mma(afr, bfr[j], acc[i][j]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: bias (+ReLU), 16-pixel slabs through LDS, 16-byte NHWC stores ----
+    float* st = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int n = n0 + j * 16 + li; bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] + bv[j];
+                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                st[(g * 4 + r) * 68 + j * 16 + li] = v;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int y = y0 + 2 * wave + (i >> 1);
+        const int xb = x0 + (i & 1) * 16;
+        if (y < H) {
+            if (p.out_f32) {
+                float* out = reinterpret_cast<float*>(p.out);
+                for (int rr = lane >> 4; rr < 16; rr += 4) {
+                    const int x = xb + rr, n = n0 + (lane & 15) * 4;
+                    if (x < W && n < p.N) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 15) * 4);
+                        *reinterpret_cast<f32x4*>(out + (((long)b * H + y) * W + x) * p.ldc + n) = v;
+                    }
+                }
+            } else {
+                half_t* out = reinterpret_cast<half_t*>(p.out);
+                for (int rr = lane >> 3; rr < 16; rr += 8) {
+                    const int x = xb + rr, n = n0 + (lane & 7) * 8;
+                    if (x < W && n < p.N) {
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 7) * 8);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 7) * 8 + 4);
+                        half8_t o;
+                        o[0] = (half_t)lo[0]; o[1] = (half_t)lo[1]; o[2] = (half_t)lo[2]; o[3] = (half_t)lo[3];
+                        o[4] = (half_t)hi[0]; o[5] = (half_t)hi[1]; o[6] = (half_t)hi[2]; o[7] = (half_t)hi[3];
+                        *reinterpret_cast<half8_t*>(out + (((long)b * H + y) * W + x) * p.ldc + n) = o;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+// Returns -1 when the layer does not fit this kernel (caller uses the implicit-GEMM path).
+int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
+    if (p.C1 % 32 != 0 || p.C2 % 32 != 0 || p.N % 8 != 0 || p.ldc % 8 != 0 || !p.zero) return -1;
+    if (((size_t)p.out & 15) != 0) return -1;
+    static int occ = -1;
+    if (occ < 0) {
+        const char* e = getenv("CVA_CONV_OCC");
+        occ = e ? atoi(e) : 4;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) return (int)hipGetLastError();
+    }
+    const int tiles = batch * ((p.H + TH - 1) / TH) * ((p.Wd + TW - 1) / TW);
+    const dim3 grid(tiles, (p.N + 63) / 64);
+    if (occ == 2) hipLaunchKernelGGL(conv3x3_halo_kernel<2>, grid, dim3(NTH), CONV_LDS, stream, p);
+    else hipLaunchKernelGGL(conv3x3_halo_kernel<4>, grid, dim3(NTH), CONV_LDS, stream, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace cva

@@ -47,4 +47,10 @@ struct GemmParams {
 
 template <typename T> int launch_gemm(const GemmParams& p, int a_mode, hipStream_t stream);
 
+// >= 256 B of zeros in device memory (DMA source for out-of-range pieces)
+void* gemm_zero_page();
+
+// conv.hip: halo-tiled direct 3x3 convolution (fp16); GemmParams as for A_CONV3.  Returns -1 if the layer does not fit.
+int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream);
+
 }  // namespace cva

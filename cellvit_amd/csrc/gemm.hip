@@ -617,6 +617,8 @@ int dispatch_glds(const GemmParams& p, int a_mode, hipStream_t stream) {
 }
 }  // namespace
 
+void* gemm_zero_page() { return zero_page(); }
+
 template <typename T>
 int launch_gemm(const GemmParams& p_in, int a_mode, hipStream_t stream) {
     GemmParams p = p_in;

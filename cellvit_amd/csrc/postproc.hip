@@ -403,12 +403,20 @@ __global__ void k_scan_apply(const int* __restrict__ Lb, int N, const int* __res
 }
 
 __global__ void k_marker_ids(const int* __restrict__ Lb, const int* __restrict__ rank, int* __restrict__ marker,
-                             int* __restrict__ msize, int N, int max_ids) {
+                             int* __restrict__ msize, int N, int W, int max_ids) {
     const long base = (long)blockIdx.y * N;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         const int r = Lb[base + i];
         int id = 0;
-        if (r >= 0) { id = rank[base + r]; if (id <= max_ids) atomicAdd(&msize[(long)blockIdx.y * (max_ids + 1) + id], 1); }
+        if (r >= 0) {
+            id = rank[base + r];
+            const int x = i % W;
+            if (id <= max_ids && !(x > 0 && Lb[base + i - 1] >= 0)) {     // one size update per horizontal run
+                int len = 1;
+                while (x + len < W && Lb[base + i + len] >= 0) ++len;
+                atomicAdd(&msize[(long)blockIdx.y * (max_ids + 1) + id], len);
+            }
+        }
         marker[base + i] = id;
     }
 }
@@ -421,7 +429,7 @@ __global__ void k_marker_filter(int* __restrict__ marker, const int* __restrict_
         int id = marker[base + i];
         if (id > max_ids || (id && msize[(long)blockIdx.y * (max_ids + 1) + id] < object_size)) id = 0;
         marker[base + i] = id;
-        inst[base + i] = blb[base + i] ? id : 0;
+        inst[base + i] = blb[base + i] ? id : -1;       // -1 = not in the mask (reset to 0 by k_inst_stats)
     }
 }
 
@@ -429,46 +437,72 @@ __global__ void k_marker_filter(int* __restrict__ marker, const int* __restrict_
 // marker-controlled watershed: one wave = one mask component, exact (value, age, index) order
 // ------------------------------------------------------------------------------------------------
 constexpr int POOL_LDS = 1024;
+constexpr int BITMAP_WORDS = 2048;          // 65536-pixel bounding boxes keep their flood state in LDS
+typedef unsigned long long u64;
 
 struct FloodParams {
     const double* dist; const uint8_t* blb; int* inst;       // [B][N]
     const int* root1; const int* bb; const int* csize;      // component labels, bboxes, pixel counts of the mask
     const int* comp_list; const int* comp_count; int list_cap;
     int* queue_head;                                          // [B] dequeue cursors
-    double* ovf_v; unsigned* ovf_age; int* ovf_idx; int* ovf_lab; unsigned long long* ovf_cursor;   // overflow arena [B][N]
+    u64* ovf_hi; u64* ovf_lo; int* ovf_lab; u64* ovf_cursor;  // overflow arena [B][N]
     int H, W, B;
 };
 
-struct Key { double v; unsigned age; int idx; int slot; };
-
-__device__ __forceinline__ bool key_less(const Key& a, const Key& b) {
-    if (a.v != b.v) return a.v < b.v;
-    if (a.age != b.age) return a.age < b.age;
-    return a.idx < b.idx;
+// Pool entries are 128-bit keys: hi = order-preserving image of the f64 distance value, lo = age << 42 | pixel
+// index << 20 (| pool slot, OR-ed in while scanning).  Lexicographic (hi, lo) order == (value, age, index) order of
+// the oracle; (age, index) is unique per entry so the slot bits never decide.
+__device__ __forceinline__ u64 sortable_f64(double v) {
+    if (v == 0.0) v = -0.0;                                    // -0.0 == +0.0 for the reference's comparisons
+    const u64 b = (u64)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
+struct Key2 { u64 hi, lo; };
+__device__ __forceinline__ bool key_less(const Key2& a, const Key2& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
 
-__device__ __forceinline__ Key shfl_key(const Key& k, int m) {
-    Key o;
-    o.v = __shfl_xor(k.v, m); o.age = __shfl_xor(k.age, m); o.idx = __shfl_xor(k.idx, m); o.slot = __shfl_xor(k.slot, m);
-    return o;
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xf, false);
+    return ((u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void min_step(Key2& k) {
+    Key2 o; o.hi = dpp_u64<CTRL, ROWMASK>(k.hi); o.lo = dpp_u64<CTRL, ROWMASK>(k.lo);
+    if (key_less(o, k)) k = o;
+}
+__device__ __forceinline__ u64 readlane63(u64 v) {
+    return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+}
+// wave-wide minimum in VALU data-parallel primitives (6 DPP steps, no LDS round trips)
+__device__ __forceinline__ Key2 wave_min_key(Key2 k) {
+    min_step<0xb1, 0xf>(k);     // quad_perm [1,0,3,2]
+    min_step<0x4e, 0xf>(k);     // quad_perm [2,3,0,1]
+    min_step<0x114, 0xf>(k);    // row_shr:4
+    min_step<0x118, 0xf>(k);    // row_shr:8
+    min_step<0x142, 0xa>(k);    // row_bcast:15
+    min_step<0x143, 0xc>(k);    // row_bcast:31
+    Key2 r; r.hi = readlane63(k.hi); r.lo = readlane63(k.lo);
+    return r;
 }
 
 __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
-    __shared__ double s_v[POOL_LDS];
-    __shared__ unsigned s_age[POOL_LDS];
-    __shared__ int s_idx[POOL_LDS];
+    __shared__ u64 s_hi[POOL_LDS];
+    __shared__ u64 s_lo[POOL_LDS];
     __shared__ int s_lab[POOL_LDS];
+    __shared__ unsigned s_bits[BITMAP_WORDS];      // claimable (unlabeled mask) pixels of the component's bbox
     const int lane = threadIdx.x;
     const int N = p.H * p.W, W = p.W, H = p.H;
     {
         const int tile = blockIdx.y;
         const long base = (long)tile * N;
         const double* dist = p.dist + base;
-        const uint8_t* blb = p.blb + base;
         int* inst = p.inst + base;
         const int* root1 = p.root1 + base;
         const int* y0a = p.bb + base * 4; const int* y1a = y0a + N; const int* x0a = y1a + N; const int* x1a = x0a + N;
-        double* ov = p.ovf_v + base; unsigned* oage = p.ovf_age + base; int* oidx = p.ovf_idx + base; int* olab = p.ovf_lab + base;
+        u64* ohi = p.ovf_hi + base; u64* olo = p.ovf_lo + base; int* olab = p.ovf_lab + base;
         int ncomp = p.comp_count[tile];
         if (ncomp > p.list_cap) ncomp = p.list_cap;
         for (;;) {
@@ -483,24 +517,25 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
             int n = 0;                 // pool size (wave uniform)
             long ovf_base = -1;        // lazily reserved slice of the overflow arena
             unsigned age = 0;
+            const bool use_bits = barea <= BITMAP_WORDS * 32;   // else: state lives in global memory (atomicCAS)
 
-            auto put = [&](int slot, double v, unsigned a, int idx, int lab) {
-                if (slot < POOL_LDS) { s_v[slot] = v; s_age[slot] = a; s_idx[slot] = idx; s_lab[slot] = lab; }
-                else { const long o = ovf_base + (slot - POOL_LDS); ov[o] = v; oage[o] = a; oidx[o] = idx; olab[o] = lab; }
+            auto put = [&](int slot, u64 hi, u64 lo, int lab) {
+                if (slot < POOL_LDS) { s_hi[slot] = hi; s_lo[slot] = lo; s_lab[slot] = lab; }
+                else { const long o = ovf_base + (slot - POOL_LDS); ohi[o] = hi; olo[o] = lo; olab[o] = lab; }
             };
-            // append entries of the active lanes in lane order (wave-uniform bookkeeping)
+            // append the entries of the active lanes in lane order (wave-uniform bookkeeping)
             auto append = [&](bool have, double v, unsigned a, int idx, int lab) {
-                const unsigned long long m = __ballot(have);
+                const u64 m = __ballot(have);
                 const int cnt = __popcll(m);
                 if (cnt == 0) return;
                 if (n + cnt > POOL_LDS && ovf_base < 0) {
-                    unsigned long long o = 0;
-                    if (lane == 0) o = atomicAdd(&p.ovf_cursor[tile], (unsigned long long)carea);   // sum over components <= N
+                    u64 o = 0;
+                    if (lane == 0) o = atomicAdd(&p.ovf_cursor[tile], (u64)carea);   // sum over components <= N
                     ovf_base = (long)__shfl((long long)o, 0);
                 }
                 if (have) {
                     const int rank = __popcll(m & ((1ull << lane) - 1ull));
-                    put(n + rank, v, a, idx, lab);
+                    put(n + rank, sortable_f64(v), ((u64)a << 42) | ((u64)(unsigned)idx << 20), lab);
                 }
                 n += cnt;
             };
@@ -514,10 +549,16 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                     const int yy = by0 + t / bw, xx = bx0 + (t - (t / bw) * bw);
                     idx = yy * W + xx;
                     if (root1[idx] == root && (lab = inst[idx]) > 0) {
-                        const bool open = (yy > 0 && blb[idx - W] && inst[idx - W] == 0) || (xx > 0 && blb[idx - 1] && inst[idx - 1] == 0) ||
-                                          (xx + 1 < W && blb[idx + 1] && inst[idx + 1] == 0) || (yy + 1 < H && blb[idx + W] && inst[idx + W] == 0);
+                        const bool open = (yy > 0 && inst[idx - W] == 0) || (xx > 0 && inst[idx - 1] == 0) ||
+                                          (xx + 1 < W && inst[idx + 1] == 0) || (yy + 1 < H && inst[idx + W] == 0);
                         if (open) { have = true; v = dist[idx]; }
                     }
+                }
+                if (use_bits) {   // 64 consecutive bbox pixels -> two bitmap words, no atomics
+                    const bool claimable = t < barea && root1[idx] == root && lab == 0 && inst[idx] == 0;
+                    const u64 cm = __ballot(claimable);
+                    if (lane == 0) s_bits[t0 >> 5] = (unsigned)cm;
+                    if (lane == 32) s_bits[(t0 >> 5) + 1] = (unsigned)(cm >> 32);
                 }
                 append(have, v, 0u, idx, lab);
             }
@@ -525,30 +566,26 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
 
             // ---- ordered flood ----
             while (n > 0) {
-                Key best; best.v = 0; best.age = 0xffffffffu; best.idx = 0x7fffffff; best.slot = -1;
-                for (int s = lane; s < n; s += 64) {
-                    Key k;
-                    if (s < POOL_LDS) { k.v = s_v[s]; k.age = s_age[s]; k.idx = s_idx[s]; }
-                    else { const long o = ovf_base + (s - POOL_LDS); k.v = ov[o]; k.age = oage[o]; k.idx = oidx[o]; }
-                    k.slot = s;
-                    if (best.slot < 0 || key_less(k, best)) best = k;
+                Key2 best; best.hi = ~0ull; best.lo = ~0ull;
+                for (int sl = lane; sl < n; sl += 64) {
+                    Key2 k;
+                    if (sl < POOL_LDS) { k.hi = s_hi[sl]; k.lo = s_lo[sl]; }
+                    else { const long o = ovf_base + (sl - POOL_LDS); k.hi = ohi[o]; k.lo = olo[o]; }
+                    k.lo |= (u64)sl;
+                    if (key_less(k, best)) best = k;
                 }
-#pragma unroll
-                for (int m = 32; m > 0; m >>= 1) {
-                    const Key o = shfl_key(best, m);
-                    if (o.slot >= 0 && (best.slot < 0 || key_less(o, best))) best = o;
-                }
+                best = wave_min_key(best);
                 // winner: identical on all lanes
-                const int ps = best.slot, pidx = best.idx;
+                const int ps = (int)(best.lo & 0xFFFFFull), pidx = (int)((best.lo >> 20) & 0x3FFFFFull);
                 int plab;
                 if (ps < POOL_LDS) plab = s_lab[ps]; else plab = olab[ovf_base + (ps - POOL_LDS)];
                 // remove: move the last entry into the hole
                 const int last = n - 1;
                 if (ps != last && lane == 0) {
-                    double lv; unsigned la; int li, ll;
-                    if (last < POOL_LDS) { lv = s_v[last]; la = s_age[last]; li = s_idx[last]; ll = s_lab[last]; }
-                    else { const long o = ovf_base + (last - POOL_LDS); lv = ov[o]; la = oage[o]; li = oidx[o]; ll = olab[o]; }
-                    put(ps, lv, la, li, ll);
+                    u64 lh, ll; int lb;
+                    if (last < POOL_LDS) { lh = s_hi[last]; ll = s_lo[last]; lb = s_lab[last]; }
+                    else { const long o = ovf_base + (last - POOL_LDS); lh = ohi[o]; ll = olo[o]; lb = olab[o]; }
+                    put(ps, lh, ll, lb);
                 }
                 n = last;
                 // neighbours in skimage order: -W, -1, +1, +W ; claim with a coherent CAS
@@ -560,10 +597,20 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                     const int yy = py + dy, xx = px + dx;
                     if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
                         q = yy * W + xx;
-                        if (blb[q] && atomicCAS(&inst[q], 0, plab) == 0) { have = true; qv = dist[q]; }
+                        qv = dist[q];                                     // issued together with the claim
+                        if (use_bits) {
+                            if (yy >= by0 && yy <= by1 && xx >= bx0 && xx <= bx1) {
+                                const int loc = (yy - by0) * bw + (xx - bx0);
+                                const unsigned bit = 1u << (loc & 31);
+                                have = (atomicAnd(&s_bits[loc >> 5], ~bit) & bit) != 0;   // LDS test-and-clear
+                                if (have) inst[q] = plab;                 // fire-and-forget: nobody reads it back
+                            }
+                        } else {
+                            have = atomicCAS(&inst[q], 0, plab) == 0;     // 0 = unlabeled mask pixel (-1 = outside)
+                        }
                     }
                 }
-                const unsigned long long m = __ballot(have);
+                const u64 m = __ballot(have);
                 const unsigned myage = age + 1u + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the hole fill above precedes the appends
                 append(have, qv, myage, q, plab);
@@ -582,14 +629,14 @@ struct StatArrays {       // all [B][max_ids + 1] unless noted
     int* rmin; int* rmax; int* cmin; int* cmax; int* first; unsigned* hist /* [..][8] */; int* has_zero /* [B] */;
 };
 
-__global__ void k_inst_stats(const int* __restrict__ inst, const uint8_t* __restrict__ type, StatArrays st, int H, int W,
+__global__ void k_inst_stats(int* __restrict__ inst, const uint8_t* __restrict__ type, StatArrays st, int H, int W,
                              int max_ids, int nr_types) {
     const int N = H * W, tile = blockIdx.y;
     const long base = (long)tile * N, sb = (long)tile * (max_ids + 1);
     bool zero_seen = false;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         const int id = inst[base + i];
-        if (id <= 0) { zero_seen = true; continue; }
+        if (id <= 0) { zero_seen = true; if (id < 0) inst[base + i] = 0; continue; }
         if (id > max_ids) continue;
         const int y = i / W, x = i - y * W;
         if (x > 0 && inst[base + i - 1] == id) continue;     // one thread per horizontal run of the instance
@@ -765,7 +812,7 @@ struct PostprocWorkspace {
     uint8_t *blb = nullptr, *mk = nullptr, *mk2 = nullptr;
     double *partial = nullptr, *params_hv = nullptr, *params_sob = nullptr, *tmp_h = nullptr, *tmp_v = nullptr, *sob = nullptr,
            *d0 = nullptr, *dist = nullptr, *ovf_v = nullptr;
-    unsigned* ovf_age = nullptr; int *ovf_idx = nullptr, *ovf_lab = nullptr;
+    unsigned long long* ovf_lo = nullptr; int* ovf_lab = nullptr;
     unsigned long long* ovf_cursor = nullptr;
     StatArrays st{};
     int list_cap = 0, nblk = 0;
@@ -791,7 +838,7 @@ int pp_workspace_create(const PostprocDims& d, PostprocWorkspace** out) {
          A((void**)&w->mk2, B * N) && A((void**)&w->partial, B * 2 * RED_BLOCKS * 2 * 8) && A((void**)&w->params_hv, B * 4 * 8) &&
          A((void**)&w->params_sob, B * 4 * 8) && A((void**)&w->tmp_h, B * N * 8) && A((void**)&w->tmp_v, B * N * 8) &&
          A((void**)&w->sob, B * 2 * N * 8) && A((void**)&w->d0, B * N * 8) && A((void**)&w->dist, B * N * 8) &&
-         A((void**)&w->ovf_v, B * N * 8) && A((void**)&w->ovf_age, B * N * 4) && A((void**)&w->ovf_idx, B * N * 4) &&
+         A((void**)&w->ovf_v, B * N * 8) && A((void**)&w->ovf_lo, B * N * 8) &&
          A((void**)&w->ovf_lab, B * N * 4) && A((void**)&w->ovf_cursor, B * 8);
     const size_t S = B * (size_t)(d.max_ids + 1);
     ok = ok && A((void**)&w->st.cnt, S * 4) && A((void**)&w->st.sx, S * 8) && A((void**)&w->st.sy, S * 8) &&
@@ -874,13 +921,13 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     hipLaunchKernelGGL(k_scan_blocks, dim3(B), blk, 0, st, w->bsum, w->nblk, nmark);
     hipLaunchKernelGGL(k_scan_apply, dim3(w->nblk, B), blk, 0, st, w->L2, N, w->bsum, w->nblk, w->rank);
     CVA_MS(w->msize, 0, S * 4);
-    hipLaunchKernelGGL(k_marker_ids, grid, blk, 0, st, w->L2, w->rank, w->marker, w->msize, N, d.max_ids);
+    hipLaunchKernelGGL(k_marker_ids, grid, blk, 0, st, w->L2, w->rank, w->marker, w->msize, N, W, d.max_ids);
     hipLaunchKernelGGL(k_marker_filter, grid, blk, 0, st, w->marker, w->msize, object_size, w->blb, inst_out, N, d.max_ids);
     // ---- P6: ordered flood ----
     FloodParams fp{};
     fp.dist = w->dist; fp.blb = w->blb; fp.inst = inst_out; fp.root1 = w->L1; fp.bb = w->bb; fp.csize = w->csize;
     fp.comp_list = w->comp_list; fp.comp_count = comp_count; fp.list_cap = w->list_cap; fp.queue_head = queue_head;
-    fp.ovf_v = w->ovf_v; fp.ovf_age = w->ovf_age; fp.ovf_idx = w->ovf_idx; fp.ovf_lab = w->ovf_lab; fp.ovf_cursor = w->ovf_cursor;
+    fp.ovf_hi = reinterpret_cast<unsigned long long*>(w->ovf_v); fp.ovf_lo = w->ovf_lo; fp.ovf_lab = w->ovf_lab; fp.ovf_cursor = w->ovf_cursor;
     fp.H = H; fp.W = W; fp.B = B;
     hipLaunchKernelGGL(k_flood, dim3(1024, B), dim3(64), 0, st, fp);
     // ---- P7/P8: per-instance records + contours ----
