@@ -234,18 +234,27 @@ __global__ __launch_bounds__(NT) void relpos_kernel(const RelPosParams p) {
     }
 }
 
+// Only the zero-padded positions of the edge windows are touched: blockIdx.y enumerates (image, edge window),
+// the block walks that window's padded positions x channels.
 template <typename T>
 __global__ void pad_kv_kernel(const PadKVParams p) {
-    const long total = (long)p.B * p.nwy * p.nwx * p.L * p.D;
+    const int nw = p.nwy * p.nwx;
+    const int b = blockIdx.y / nw, w = blockIdx.y - b * nw;
+    const int wy = w / p.nwx, wx = w - wy * p.nwx;
+    const int vy = min(p.win, p.gh - wy * p.win), vx = min(p.win, p.gw - wx * p.win);   // valid rows / cols of this window
+    if (vy == p.win && vx == p.win) return;                                            // interior window: nothing padded
+    const int s = blockIdx.y;
+    const int npad = p.L - vy * vx;
+    const long total = (long)npad * p.D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % p.D);
-        long t = i / p.D;
-        const int pos = (int)(t % p.L);
-        const int s = (int)(t / p.L);
-        const int w = s % (p.nwy * p.nwx);
-        const int wy = w / p.nwx, wx = w - wy * p.nwx;
-        const int py = pos / p.win, px = pos - py * p.win;
-        if (wy * p.win + py < p.gh && wx * p.win + px < p.gw) continue;   // real token
+        int k = (int)(i / p.D);                      // k-th padded position of the window, row-major
+        // rows 0..vy-1 have (win - vx) padded columns each, rows vy.. are fully padded
+        int py, px;
+        const int head_pad = vy * (p.win - vx);
+        if (k < head_pad) { py = k / (p.win - vx); px = vx + (k - py * (p.win - vx)); }
+        else { k -= head_pad; py = vy + k / p.win; px = k - (k / p.win) * p.win; }
+        const int pos = py * p.win + px;
         const int h = c / p.hd, d = c - h * p.hd;
         reinterpret_cast<T*>(p.K)[(((long)s * p.heads + h) * p.L + pos) * p.hd + d] =
             Traits<T>::from_float(p.qkv_bias[p.D + c]);
@@ -298,9 +307,9 @@ int launch_relpos(const RelPosParams& p, hipStream_t stream) {
 
 template <typename T>
 int launch_pad_kv(const PadKVParams& p, hipStream_t stream) {
-    const long total = (long)p.B * p.nwy * p.nwx * p.L * p.D;
-    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL((pad_kv_kernel<T>), dim3(blocks), dim3(256), 0, stream, p);
+    const int max_pad = p.L - 1;
+    const int bx = (int)(((long)max_pad * p.D + 255) / 256 > 64 ? 64 : ((long)max_pad * p.D + 255) / 256);
+    hipLaunchKernelGGL((pad_kv_kernel<T>), dim3(bx, p.B * p.nwy * p.nwx), dim3(256), 0, stream, p);
     return (int)hipGetLastError();
 }
 

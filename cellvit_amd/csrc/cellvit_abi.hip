@@ -318,9 +318,13 @@ int run_linear(const void* A, int lda, const LinearW& w, const float* res, int l
     return CV_OK;
 }
 
+struct HeadFuse { const float* W = nullptr; const float* b = nullptr; float* logits = nullptr; uint8_t* argmax = nullptr; int nout = 0, narg = 0; };
+
+// returns CV_OK; *fused (if given) tells whether the 1x1 head ran inside the conv epilogue
 template <typename T>
 int run_conv3(const void* s1, int C1, const void* s2, int C2, const ConvW& w, void* out, int out_f32, int B, int Hs,
-              int Ws, hipStream_t st) {
+              int Ws, hipStream_t st, const HeadFuse* head = nullptr, bool* fused = nullptr) {
+    if (fused) *fused = false;
     if (C1 + C2 != w.Ctot) { cva_set_error("conv3x3 channel mismatch %d+%d vs %d", C1, C2, w.Ctot); return CV_ERR_INVALID; }
     GemmParams p{};
     p.M = B * Hs * Ws; p.N = w.Cout; p.K = w.K; p.A = s1; p.A2 = s2; p.W = w.W; p.ldw = w.ldw;
@@ -332,8 +336,14 @@ int run_conv3(const void* s1, int C1, const void* s2, int C2, const ConvW& w, vo
         static const int conv_variant = [] { const char* e = getenv("CVA_CONV"); return e ? atoi(e) : 2; }();
         if (conv_variant != 1) {
             p.zero = gemm_zero_page();
+            static const int head_fuse = [] { const char* e = getenv("CVA_HEADFUSE"); return e ? atoi(e) : 1; }();
+            if (head && head_fuse && head->nout <= 8 && w.Cout == 64) {
+                p.head_W = head->W; p.head_b = head->b; p.head_logits = head->logits; p.head_argmax = head->argmax;
+                p.head_nout = head->nout; p.head_narg = head->narg;
+            }
             const int rch = launch_conv3x3_halo(p, B, st);
-            if (rch == 0) return CV_OK;
+            if (rch == 0) { if (fused) *fused = p.head_W != nullptr; return CV_OK; }
+            p.head_W = nullptr;
             if (rch != -1) { cva_set_error("conv3x3 halo launch failed (%d)", rch); return CV_ERR_HIP; }
         }
     }
@@ -504,10 +514,15 @@ int forward_impl(cv_handle* h, const float* x, int B, const cv_outputs* out, hip
         CVA_TRY(run_conv3<T>(S1, 128, nullptr, 0, b.d1[1], S2, 0, B, 8 * gh, 8 * gw, st));
         CVA_TRY(run_convT<T>(S2, b.up1, S0, B, 8 * gh, 8 * gw, st));
         CVA_TRY(run_conv3<T>(h->skip[0], 64, S0, 64, b.d0[0], S1, 0, B, H, W, st));
-        CVA_TRY(run_conv3<T>(S1, 64, nullptr, 0, b.d0[1], S2, 0, B, H, W, st));
         float* logits = br == 0 ? out->nuclei_binary_map : br == 1 ? out->hv_map : out->nuclei_type_map;
         uint8_t* am = br == 0 ? out->binary_argmax : br == 2 ? out->type_argmax : nullptr;
         const long npix = (long)H * W;
+        HeadFuse hf; bool fused = false;
+        if (logits && !(br == 0 && c.regression_loss)) {
+            hf.W = b.head.W; hf.b = b.head.b; hf.logits = logits; hf.argmax = am; hf.nout = b.head.n_out; hf.narg = b.head.n_out;
+        }
+        CVA_TRY(run_conv3<T>(S1, 64, nullptr, 0, b.d0[1], S2, 0, B, H, W, st, hf.W ? &hf : nullptr, &fused));
+        if (fused) continue;
         if (br == 0 && c.regression_loss) {
             // binary branch carries 2 extra regression channels (cellvit.py:191-196): write the 4-channel
             // result into the scratch logits and split on the fly is not needed — emit two heads.

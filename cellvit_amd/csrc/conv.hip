@@ -28,7 +28,7 @@ constexpr int HALO_INSTR = (HALO_PIX + 15) / 16;     // 39 one-KiB DMA instructi
 constexpr int HALO_BYTES = HALO_INSTR * 1024;        // 39936
 constexpr int W_INSTR = 9 * 4;                       // 9 taps x 64 rows / 16 rows per instruction
 constexpr int W_BYTES = W_INSTR * 1024;              // 36864
-constexpr int CONV_LDS = HALO_BYTES + W_BYTES;       // 76800 -> two workgroups per CU
+constexpr int CONV_LDS = HALO_BYTES + W_BYTES;       // 76800 per stage; two stages = 153600 B, one workgroup per CU
 constexpr int NTH = 512, NWAVE = 8;
 constexpr int MAX_H = (HALO_INSTR + NWAVE - 1) / NWAVE;   // 5
 constexpr int MAX_W = (W_INSTR + NWAVE - 1) / NWAVE;      // 5
@@ -92,21 +92,22 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int n = j * 16 + li; b_off[j] = n * 64 + ((g ^ swz(n)) << 4); }
 
-    const int nchunks = ctot / 32;
-    for (int ch = 0; ch < nchunks; ++ch) {
+    // double-buffered: the DMA of chunk ch+1 is in flight while chunk ch is multiplied (one barrier per chunk)
+    auto stage = [&](int ch, int buf) {
         const int c0 = ch * 32;
         const bool second = c0 >= p.C1;
         const half_t* __restrict__ src = second ? S2 : S1;
         const int cs = second ? p.C2 : p.C1;
         const int cc = second ? c0 - p.C1 : c0;
-        __syncthreads();                              // previous chunk fully consumed
+        unsigned char* dH = sH + buf * CONV_LDS;
+        unsigned char* dW = sW + buf * CONV_LDS;
 #pragma unroll
         for (int i = 0; i < MAX_H; ++i) {
             const int k = wave + NWAVE * i;
             if (k < HALO_INSTR) {                     // wave-uniform
                 const half_t* s = h_pix[i] >= 0 ? src + (long)(h_pix[i] >> 2) * cs + cc + (h_pix[i] & 3) * 8 : Zp;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                                 (__attribute__((address_space(3))) void*)(sH + k * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dH + k * 1024), 16, 0, 0);
             }
         }
 #pragma unroll
@@ -115,30 +116,47 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
             if (k < W_INSTR) {
                 const half_t* s = w_row[i] >= 0 ? Wp + w_row[i] + c0 : Zp;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                                 (__attribute__((address_space(3))) void*)(sW + k * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dW + k * 1024), 16, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    };
+    const int nchunks = ctot / 32;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
+        const unsigned char* cH = sH + buf * CONV_LDS;
+        const unsigned char* cW = sW + buf * CONV_LDS;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             TR::Frag bfr[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = TR::load_frag(reinterpret_cast<const half_t*>(sW + tap * 4096 + b_off[j]));
+            for (int j = 0; j < 4; ++j) bfr[j] = TR::load_frag(reinterpret_cast<const half_t*>(cW + tap * 4096 + b_off[j]));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hp = a_hp[i] + dy * HW_ + dx;
-                const TR::Frag afr = TR::load_frag(reinterpret_cast<const half_t*>(sH + hp * 64 + ((g ^ swz(hp)) << 4)));
+                const TR::Frag afr = TR::load_frag(reinterpret_cast<const half_t*>(cH + hp * 64 + ((g ^ swz(hp)) << 4)));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) TR::mma(afr, bfr[j], acc[i][j]);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
     __syncthreads();
 
     // ---- epilogue: bias (+ReLU), 16-pixel slabs through LDS, 16-byte NHWC stores ----
     float* st = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+    const bool fuse = p.head_W != nullptr;
+    float* hw = reinterpret_cast<float*>(smem + 36864);       // head weights [nout][64] + bias [nout]
+    if (fuse) {
+        for (int i = tid; i < p.head_nout * 65; i += NTH)
+            hw[i] = i < p.head_nout * 64 ? p.head_W[i] : p.head_b[i - p.head_nout * 64];
+        __syncthreads();
+    }
     float bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int n = n0 + j * 16 + li; bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f; }
@@ -156,7 +174,35 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
         __builtin_amdgcn_wave_barrier();
         const int y = y0 + 2 * wave + (i >> 1);
         const int xb = x0 + (i & 1) * 16;
-        if (y < H) {
+        if (fuse) {
+            // 1x1 head on the slab: lane = (pixel rr, quarter of the 64 channels); quad reduction
+            const int rr = lane >> 2, part = lane & 3;
+            float ah[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) ah[n] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float v = st[rr * 68 + part * 16 + c];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) if (n < p.head_nout) ah[n] = fmaf(v, hw[n * 64 + part * 16 + c], ah[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) { ah[n] += __shfl_xor(ah[n], 1); ah[n] += __shfl_xor(ah[n], 2); }
+            const int x = xb + rr;
+            if (part == 0 && y < H && x < W) {
+                const long hwp = (long)H * W, pix = (long)y * W + x;
+                int best = 0; float bvv = 0.f;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    if (n < p.head_nout) {
+                        const float v = ah[n] + hw[p.head_nout * 64 + n];
+                        p.head_logits[((long)b * p.head_nout + n) * hwp + pix] = v;
+                        if (n == 0) bvv = v; else if (n < p.head_narg && v > bvv) { bvv = v; best = n; }
+                    }
+                }
+                if (p.head_argmax) p.head_argmax[(long)b * hwp + pix] = (uint8_t)best;
+            }
+        } else if (y < H) {
             if (p.out_f32) {
                 float* out = reinterpret_cast<float*>(p.out);
                 for (int rr = lane >> 4; rr < 16; rr += 4) {
@@ -191,11 +237,12 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
 // Returns -1 when the layer does not fit this kernel (caller uses the implicit-GEMM path).
 int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
     if (p.C1 % 32 != 0 || p.C2 % 32 != 0 || p.N % 8 != 0 || p.ldc % 8 != 0 || !p.zero) return -1;
-    if (((size_t)p.out & 15) != 0) return -1;
+    if (p.head_W) { if (p.N != 64 || p.head_nout < 1 || p.head_nout > 8 || !p.head_logits) return -1; }
+    else if (((size_t)p.out & 15) != 0 || !p.out) return -1;
     static int occ = -1;
     if (occ < 0) {
         const char* e = getenv("CVA_CONV_OCC");
-        occ = e ? atoi(e) : 4;
+        occ = e ? atoi(e) : 2;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -203,8 +250,8 @@ int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
     }
     const int tiles = batch * ((p.H + TH - 1) / TH) * ((p.Wd + TW - 1) / TW);
     const dim3 grid(tiles, (p.N + 63) / 64);
-    if (occ == 2) hipLaunchKernelGGL(conv3x3_halo_kernel<2>, grid, dim3(NTH), CONV_LDS, stream, p);
-    else hipLaunchKernelGGL(conv3x3_halo_kernel<4>, grid, dim3(NTH), CONV_LDS, stream, p);
+    if (occ == 2) hipLaunchKernelGGL(conv3x3_halo_kernel<2>, grid, dim3(NTH), 2 * CONV_LDS, stream, p);
+    else hipLaunchKernelGGL(conv3x3_halo_kernel<4>, grid, dim3(NTH), 2 * CONV_LDS, stream, p);
     return (int)hipGetLastError();
 }
 

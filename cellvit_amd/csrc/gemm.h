@@ -41,6 +41,9 @@ struct GemmParams {
     int D, hd, heads, ntok, L, Lp;   // ntok tokens per image (incl. cls for ViT)
     int win, gw, gh, nwx, nwy;       // win > 0: window partition of the gh x gw token grid
     const void* zero;                // >= 16 B of zeros in device memory (filled in by launch_gemm)
+    // conv3x3 halo kernel only: fused 1x1 output head (cellvit.py:309-315) on the ReLU output; the 64-channel
+    // activation itself is then not written (out may be null).  logits fp32 NCHW [B, nout, H, W], argmax u8 [B, H, W].
+    const float* head_W; const float* head_b; float* head_logits; uint8_t* head_argmax; int head_nout, head_narg;
     int epi_vec;                     // 1: LDS-staged 16-byte epilogue stores (set by launch_gemm)
     int dbg;                         // experiment switches (CVA_GEMM_DBG): 1 no staging, 2 no LDS reads, 4 no L2 prefetch
 };
