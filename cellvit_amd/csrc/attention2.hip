@@ -54,7 +54,9 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     using Frag = typename TR::Frag;
     constexpr int PE = TR::PIECE;
     constexpr int HDP = (HD + 31) / 32 * 32, NKS = HDP / 32, ND = HD / 16;
-    constexpr int PK = lds_pitch<T>(HDP), PV = lds_pitch<T>(KT);
+    // V^T rows are read as 8-byte halves of a fragment (two ds_read_b64 per lane): a 144-byte pitch spreads the 16
+    // rows of a lane group over distinct bank pairs (160 B would alias rows r and r+8).
+    constexpr int PK = lds_pitch<T>(HDP), PV = sizeof(T) == 2 ? KT + 8 : lds_pitch<T>(KT);
     constexpr int EW = NBK * 32;                       // one-hot width (BIAS 1)
     constexpr int PE1 = lds_pitch<T>(EW);              // pitch of E and relcat rows (BIAS 1)
     constexpr int RC2 = 128 + 8;                       // relcat row pitch (BIAS 2): KH + KW <= 128
@@ -169,30 +171,51 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
         for (int n = 0; n < ND; ++n) o[qb][n] = (f32x4)(0.f);
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
-    const int ntiles = (p.nk + KT - 1) / KT;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-        {   // K tile
-            constexpr int PPR = HD / PE;
-            for (int i = tid; i < KT * PPR; i += NT) {
-                const int r = i / PPR, c = i - r * PPR;
-                const int key = kt * KT + r;
-                store_piece(Ks + r * PK + c * PE, key < p.nk ? load_piece(Kg + (long)key * HD + c * PE) : zero_piece());
-            }
+    // K / V^T tiles are fetched one tile ahead into registers (issue early, write to LDS after the barrier):
+    // the global-memory latency of tile kt+1 hides behind the MFMAs of tile kt.
+    constexpr int KPPR = HD / PE, VPPR = KT / PE;
+    constexpr int KN = (KT * KPPR + NT - 1) / NT, VN = (HD * VPPR + NT - 1) / NT;
+    Piece kreg[KN], vreg[VN];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < KN; ++u) {
+            const int i = tid + u * NT;
+            const int r = i / KPPR, c = i - r * KPPR;
+            const int key = kt * KT + r;
+            kreg[u] = (i < KT * KPPR && key < p.nk) ? load_piece(Kg + (long)key * HD + c * PE) : zero_piece();
         }
-        {   // V^T tile
-            constexpr int PPR = KT / PE;
-            for (int i = tid; i < HD * PPR; i += NT) {
-                const int d = i / PPR, c = i - d * PPR;
-                const int key0 = kt * KT + c * PE;
-                Piece v = load_piece(Vg + (long)d * p.Lp + key0);
-                if (key0 + PE > p.nk) {
+#pragma unroll
+        for (int u = 0; u < VN; ++u) {
+            const int i = tid + u * NT;
+            const int d = i / VPPR, c = i - d * VPPR;
+            const int key0 = kt * KT + c * PE;
+            Piece v = zero_piece();
+            if (i < HD * VPPR) {
+                v = load_piece(Vg + (long)d * p.Lp + key0);
+                if (key0 + PE > p.nk) {                 // never let stale bytes past the last key meet P = 0
                     T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
                     for (int j = 0; j < PE; ++j) if (key0 + j >= p.nk) e[j] = TR::from_float(0.f);
                 }
-                store_piece(Vts + d * PV + c * PE, v);
             }
+            vreg[u] = v;
+        }
+    };
+    const bool wave_active = q0 < p.L;                 // waves whose 32 queries are all padding only help staging
+
+    const int ntiles = (p.nk + KT - 1) / KT;
+    fetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < KN; ++u) {
+            const int i = tid + u * NT;
+            if (i < KT * KPPR) { const int r = i / KPPR, c = i - r * KPPR; store_piece(Ks + r * PK + c * PE, kreg[u]); }
+        }
+#pragma unroll
+        for (int u = 0; u < VN; ++u) {
+            const int i = tid + u * NT;
+            if (i < HD * VPPR) { const int d = i / VPPR, c = i - d * VPPR; store_piece(Vts + d * PV + c * PE, vreg[u]); }
         }
         if (BIAS == 1) {   // one-hot rows E[key][kh] = E[key][KH + kw] = 1
             constexpr int PPR = EW / PE;
@@ -213,12 +236,16 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             }
         }
         __syncthreads();
+        if (kt + 1 < ntiles) fetch(kt + 1);
+        if (!wave_active) continue;
+        const int nkb = min(4, (p.nk - kt * KT + 15) / 16);      // key blocks of this tile that hold real keys
 
         // ---- S^T blocks: s[qb][kb][r] = score(query li of qb, key kb*16 + g*4 + r) / scale ----
         f32x4 s[2][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             s[0][kb] = (f32x4)(0.f); s[1][kb] = (f32x4)(0.f);
+            if (kb >= nkb) continue;                              // wave-uniform: masked to -inf below
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const Frag kf = TR::load_frag(Ks + (kb * 16 + li) * PK + ks * 32 + g * 8);
@@ -278,6 +305,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
         // ---- O^T += V^T P^T : A = V^T rows d = n*16 + li, keys (2m)*16 + g*4 + {0..3} and (2m+1)*16 + g*4 + {0..3} ----
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
+            if (2 * m >= nkb) continue;                           // all P of these 32 keys are exactly 0
 #pragma unroll
             for (int n = 0; n < ND; ++n) {
                 const T* vrow = Vts + (n * 16 + li) * PV + g * 4;
@@ -321,7 +349,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
 template <typename T, int HD, int BIAS, int NBK>
 int launch_attn2_impl(const AttnParams& p, hipStream_t stream) {
     constexpr int HDP = (HD + 31) / 32 * 32;
-    size_t lds = (size_t)(KT * lds_pitch<T>(HDP) + HD * lds_pitch<T>(KT)) * sizeof(T);
+    size_t lds = (size_t)(KT * lds_pitch<T>(HDP) + HD * lds_pitch<T>(KT)) * sizeof(T);   // (V^T pitch <= lds_pitch)
     if (BIAS == 1) lds += (size_t)(KT + QT) * lds_pitch<T>(NBK * 32) * sizeof(T);
     if (BIAS == 2) lds += (size_t)QT * (128 + 8) * sizeof(T);
     static bool attr_set = false;

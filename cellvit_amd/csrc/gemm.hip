@@ -240,6 +240,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
 }
 
 
+// grouped rasterisation: consecutive ids walk GM tile rows of one tile column before moving to the next
+// column, so the blocks resident on one XCD at a time share few distinct A and W panels (L2 hits).
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int group = id / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(GM, tiles_m - first_m);
+    const int within = id - group * per_group;
+    tm = first_m + within % gsz;
+    tn = within / gsz;
+}
+
 template <typename T, int AMODE, int OMODE>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     using TR = Traits<T>;
@@ -256,8 +269,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    int tm_, tn_;
+    if (p.dbg & 16) { const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n); tm_ = bid / tiles_n; tn_ = bid % tiles_n; }
+    else tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm_, tn_);
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
 
     const int pc = tid % PPR, pr = tid / PPR;
     const T* __restrict__ Ap = reinterpret_cast<const T*>(p.A);
@@ -375,19 +390,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
 // one 128-B line: global coalescing is unchanged.  Out-of-range rows / K tail read a zero page.
 // One barrier per K tile; the next tile's DMA is in flight while the current one is multiplied.
 // ================================================================================================
-// grouped rasterisation: consecutive ids walk GM tile rows of one tile column before moving to the next
-// column, so the blocks resident on one XCD at a time share few distinct A and W panels (L2 hits).
-__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
-    constexpr int GM = 8;
-    const int per_group = GM * tiles_n;
-    const int group = id / per_group;
-    const int first_m = group * GM;
-    const int gsz = min(GM, tiles_m - first_m);
-    const int within = id - group * per_group;
-    tm = first_m + within % gsz;
-    tn = within / gsz;
-}
-
 template <typename T, int AMODE, int OMODE, int WMW, int WNW, int MI, int NJ>
 __global__ __launch_bounds__(WMW * WNW * 64) void gemm_glds_kernel(const GemmParams p) {
     using TR = Traits<T>;
