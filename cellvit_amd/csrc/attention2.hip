@@ -145,6 +145,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     }
     __syncthreads();
 
+    const float c1 = p.scale * LOG2E;                  // relcat holds bias / scale, so bias * log2e = relcat * c1
     // BIAS 1: Q-side bias fragments (rows of relcat);  BIAS 2: tile-invariant kw terms in registers
     Frag bf[2][NBK];
     float bw[2][4][4];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    bw[qb][kb][r] = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + p.KH + kb * 16 + g * 4 + r]) * p.scale;
+                    bw[qb][kb][r] = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + p.KH + kb * 16 + g * 4 + r]) * c1;
     }
 
     f32x4 o[2][ND];
@@ -262,34 +263,35 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             }
         }
         // ---- online softmax per query (lane-local + the 4 lanes li, li+16, li+32, li+48) ----
+        // everything in the log2 domain: v = s * (scale*log2e) + bias*log2e ; p = 2^(v - m)
+        const bool ragged = (kt == ntiles - 1) && (p.nk & (KT - 1)) != 0;     // only the last tile can hold invalid keys
         Frag pf[2][2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             float bh = 0.f;
-            if (BIAS == 2) bh = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + kt]) * p.scale;   // kh == kt
+            if (BIAS == 2) bh = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + kt]) * c1;   // kh == kt
             float mx = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kt * KT + kb * 16 + g * 4 + r;
-                    float v = s[qb][kb][r] * p.scale;
+                    float v = s[qb][kb][r] * c1;
                     if (BIAS == 2) v += bw[qb][kb][r] + bh;
-                    v = key < p.nk ? v : -INFINITY;
+                    if (ragged) { const int key = kt * KT + kb * 16 + g * 4 + r; v = key < p.nk ? v : -INFINITY; }
                     s[qb][kb][r] = v;
                     mx = fmaxf(mx, v);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mn = fmaxf(m_run[qb], mx);
-            const float alpha = exp2f((m_run[qb] - mn) * LOG2E);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - mn);
             m_run[qb] = mn;
             float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2f((s[qb][kb][r] - mn) * LOG2E);
+                    const float pv = __builtin_amdgcn_exp2f(s[qb][kb][r] - mn);
                     rs += pv;
                     // contraction slot (m, g*8 + j): j < 4 -> key block 2m, reg j ; j >= 4 -> key block 2m+1, reg j-4
                     set_frag<T>(pf[qb][kb >> 1], (kb & 1) * 4 + r, pv);
