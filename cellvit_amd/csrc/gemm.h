@@ -39,6 +39,7 @@ struct GemmParams {
     // OUT_QKV: scatter q,k -> [S*heads, L, hd], v -> V^T [S*heads, hd, Lp]
     void* q_out; void* k_out; void* vt_out;
     int D, hd, heads, ntok, L, Lp;   // ntok tokens per image (incl. cls for ViT)
+    int n_off;                       // OUT_QKV: column n of this launch is column n + n_off of the fused qkv projection
     int win, gw, gh, nwx, nwy;       // win > 0: window partition of the gh x gw token grid
     const void* zero;                // >= 16 B of zeros in device memory (filled in by launch_gemm)
     // conv3x3 halo kernel only: fused 1x1 output head (cellvit.py:309-315) on the ReLU output; the 64-channel
@@ -49,6 +50,10 @@ struct GemmParams {
 };
 
 template <typename T> int launch_gemm(const GemmParams& p, int a_mode, hipStream_t stream);
+
+// gemm8.hip: 256x256x64 8-phase fp16 kernel (A_LINEAR only); launch_gemm routes to it when the shape qualifies.
+bool gemm8_supported(const GemmParams& p, int a_mode, size_t elem_size);
+int launch_gemm8(const GemmParams& p, hipStream_t stream);
 
 // >= 256 B of zeros in device memory (DMA source for out-of-range pieces)
 void* gemm_zero_page();

@@ -1,0 +1,398 @@
+// 256 x 256 x 64 fp16 MFMA contraction with an 8-phase, two-K-tiles-per-iteration schedule (gfx950).
+//
+// 512 threads = 8 waves laid out 2 (M) x 4 (N); every wave owns a 128 x 64 block of C = 8 x 4
+// accumulator fragments (128 VGPRs) and walks it one 64 x 32 quadrant (16 MFMAs) per phase.
+//
+// LDS (128 KiB, one workgroup per CU): two K-tile buffers E / O, each holding the A tile (256 rows x
+// 128 B) and the W tile (256 rows x 128 B).  Tiles are written by the direct-to-LDS DMA
+// (global_load_lds, 1 KiB = 8 rows per wave instruction, 4 instructions per wave and tile) and are
+// swizzled on the SOURCE side exactly as in gemm.hip: lane l fetches logical 16-B piece
+// (l&7) ^ ((row>>1)&7) of its row, fragment reads apply the same involution (bank-conflict free).
+//
+// Phase p = { ds_read the operand sub-tile the NEXT phase needs; issue one tile of DMA; barrier;
+//             16 MFMAs at raised priority; barrier }.  The two M wave groups run one barrier apart, so
+// one group's LDS reads / DMA issue overlap the other group's MFMAs on the same SIMDs, and every
+// fragment read has a whole phase to land before its MFMAs issue (counted lgkmcnt, placed by the compiler).
+// Register roles: A0 / A1 hold the A sub-tiles (rows 0-63 / 64-127 of the wave block), X / Y the W sub-tiles;
+// X and Y swap roles every K tile so that the first quadrant of the next tile can be fetched one phase early.
+//
+//   phase  MFMA quadrant  operands   reads issued (for the next phase)        DMA issued           counted wait
+//   1      (0,0)          A0, X      Y  <- E.W sub 1
+//   2      (0,1)          A0, Y      A1 <- E.A sub 1
+//   3      (1,1)          A1, Y      -                                        E.W <- tile kt+2     vmcnt(4): O complete
+//   4      (1,0)          A1, X      A0 <- O.A sub 0, Y <- O.W sub 0          E.A <- tile kt+2
+//   5      (0,0)          A0, Y      X  <- O.W sub 1
+//   6      (0,1)          A0, X      A1 <- O.A sub 1
+//   7      (1,1)          A1, X      -                                        O.W <- tile kt+3     vmcnt(4): E complete
+//   8      (1,0)          A1, Y      A0 <- E.A sub 0, X <- E.W sub 0          O.A <- tile kt+3
+//
+// Hazard rules the table obeys (barrier epochs, with the half-phase stagger between the wave groups):
+//   WAR  a tile is re-staged >= 2 phases after its last ds_read (E.W: 1 -> 3, E.A: 2 -> 4, O.W: 5 -> 7, O.A: 6 -> 8);
+//   RAW  a staged tile is read >= 1 phase after the counted vmcnt that retires it (O: wait in 3, read from 4;
+//        E: wait in 7, read from 8).  vmcnt never drops to 0 inside the loop: one tile of DMA (4 loads per
+//        lane) is always left in flight across the barriers.
+// (Measured: mixing ordinary VGPR loads, e.g. an L2 prefetch touch, into the same vmcnt stream breaks the counted
+//  waits — LDS-DMA loads and VGPR loads do not retire in order with respect to each other.)
+#include "gemm.h"
+#include "gemm_epilogue.h"
+
+namespace cva {
+
+namespace {
+
+using namespace epi;
+
+constexpr int G8_BM = 256, G8_BN = 256, G8_BK = 64, G8_NT = 512;
+constexpr int G8_TILE = 256 * 128;          // bytes of one A or W tile (256 rows x 128 B)
+constexpr int G8_WOFF = 2 * G8_TILE;        // LDS layout: [E.A][O.A][E.W][O.W] -> buffer select = +32 KiB immediate offset
+constexpr int G8_LDS = 4 * G8_TILE;
+
+#define G8_BAR()                                   \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_barrier();              \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+
+#define G8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// 16 MFMAs of quadrant (MH, NH): C[MH*4+mi][NH*2+nj] += A[mi][ks] * W[nj][ks]
+#define G8_MMQ(n, a, b, MH, NH)                                                                             \
+    do {                                                                                                  \
+        G8_WAIT(n, a, b);                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
+                _Pragma("unroll") for (int nj = 0; nj < 2; ++nj)                                          \
+                    acc[(MH) * 4 + mi][(NH) * 2 + nj] =                                                   \
+                        TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(b[nj][ks], a[mi][ks],              \
+                                                                       acc[(MH) * 4 + mi][(NH) * 2 + nj], 0, 0, 0) \
+                              : __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][ks], b[nj][ks],              \
+                                                                       acc[(MH) * 4 + mi][(NH) * 2 + nj], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                    \
+    } while (0)
+
+// Pin a wave-uniform pointer into SGPRs (opaque to the optimiser): the DMA then uses the
+// `global_load_lds v_off, s[base:base+1]` form instead of per-lane 64-bit induction pointers.
+__device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char* q) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+}
+
+
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the
+// fp16 rounding of the result).  Written in erfc form so that large negative x does not cancel:
+//   q = 0.5 x P(t) exp(-x^2/2), t = 1 / (1 + 0.3275911 |x| / sqrt 2);   gelu = x >= 0 ? x - q : q.
+__device__ __forceinline__ float gelu_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678f, 1.0f));
+    float pl = fmaf(t, 1.061405429f, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    pl *= t;
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504089f));
+    const float q = 0.5f * x * pl * e;
+    return x >= 0.f ? x - q : q;
+}
+
+// Direct epilogue for the TRANSPOSED accumulator orientation (C^T fragments: lane (g, li) holds, for row
+// m = i*16 + li of the wave block, the 16 CONSECUTIVE columns g*16 .. g*16+15 — the W rows are permuted at DMA
+// time to make them consecutive).  No LDS: bias / activation / residual on registers, 16-byte stores.
+template <int OMODE>
+__device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&acc)[8][4], const int mrow0, const int ncol0,
+                                                 const int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    const int n = ncol0 + g * 16;
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 b4 = (f32x4)(0.f);
+        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + n + q * 4);
+        bv[q * 4 + 0] = b4[0]; bv[q * 4 + 1] = b4[1]; bv[q * 4 + 2] = b4[2]; bv[q * 4 + 3] = b4[3];
+    }
+    half_t* qk = nullptr;
+    long col_term = 0;
+    if (OMODE == OUT_QKV) {
+        const int nn = n + p.n_off;
+        const int which = nn / p.D;
+        const int c = nn - which * p.D;
+        const int h = c / p.hd, d = c - h * p.hd;           // 16 consecutive d inside one head (hd % 16 == 0)
+        qk = reinterpret_cast<half_t*>(which == 0 ? p.q_out : p.k_out);
+        col_term = (long)h * p.L * p.hd + d;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = mrow0 + i * 16 + li;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] + bv[j * 4 + r];
+                if (p.act == ACT_GELU) x = gelu_as(x);
+                else if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+                v[j * 4 + r] = x;
+            }
+        if (OMODE == OUT_LINEAR) {
+            long orow = m;
+            if (p.o_rpi > 0) orow = (long)m + (long)(m / p.o_rpi) * p.o_extra + p.o_off;
+            if (p.res) {
+                const long rrow = p.res_mod > 0 ? (long)(m % p.res_mod) : orow;
+                const float* rp = p.res + rrow * p.ldres + n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(rp + q * 4);
+                    v[q * 4 + 0] += r4[0]; v[q * 4 + 1] += r4[1]; v[q * 4 + 2] += r4[2]; v[q * 4 + 3] += r4[3];
+                }
+            }
+            if (p.out_f32) {
+                float* o = reinterpret_cast<float*>(p.out) + orow * (long)p.ldc + n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = {v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+                    *reinterpret_cast<f32x4*>(o + q * 4) = w;
+                }
+            } else {
+                half_t* o = reinterpret_cast<half_t*>(p.out) + orow * (long)p.ldc + n;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    half8_t w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
+                    *reinterpret_cast<half8_t*>(o + q * 8) = w;
+                }
+            }
+        } else {   // OUT_QKV, q or k columns
+            const int b = m / p.ntok, t = m - b * p.ntok;
+            int s_ = b, pos = t;
+            if (p.win > 0) {
+                const int gy = t / p.gw, gx = t - gy * p.gw;
+                const int wy = gy / p.win, wx = gx / p.win;
+                s_ = (b * p.nwy + wy) * p.nwx + wx;
+                pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
+            }
+            half_t* o = qk + ((long)s_ * p.heads * p.L + pos) * p.hd + col_term;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                half8_t w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
+                *reinterpret_cast<half8_t*>(o + q * 8) = w;
+            }
+        }
+    }
+}
+
+template <int OMODE, int TRANS, int ABL>
+__global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = p.N / G8_BN, tiles_m = p.M / G8_BM;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * G8_BM, n0 = tn * G8_BN;
+
+    // ---- DMA source offsets (bytes, 32-bit; host guarantees they fit) of the 4 A rows and 4 W rows this lane stages
+    const int lrow = lane >> 3, lpc = lane & 7;
+    unsigned a_voff[4], w_voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + lrow;
+        const int lp = lpc ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        long r = m;
+        if (p.a_rpi > 0) r = (long)m + (long)(m / p.a_rpi) * p.a_extra + p.a_off;
+        a_voff[i] = (unsigned)((r * (long)p.lda + lp * 8) * 2);
+        // TRANS: LDS row wc*64 + j*16 + g*4 + r holds W row wc*64 + g*16 + j*4 + r, so that a lane's 16 accumulator
+        // values per output row are 16 consecutive columns (see epilogue8_direct)
+        const int wrow = TRANS ? ((row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3)) : row;
+        w_voff[i] = (unsigned)(((long)(n0 + wrow) * p.ldw + lp * 8) * 2);
+    }
+    const unsigned char* __restrict__ Ab = reinterpret_cast<const unsigned char*>(p.A);
+    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.W);
+
+    auto stage_a = [&](int buf, int kt) {
+        const unsigned char* base = uniform_ptr(Ab + (long)kt * (G8_BK * 2));
+        unsigned char* dst = smem8 + buf * G8_TILE + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + a_voff[i]),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+    auto stage_w = [&](int buf, int kt) {
+        const unsigned char* base = uniform_ptr(Wb + (long)kt * (G8_BK * 2));
+        unsigned char* dst = smem8 + G8_WOFF + buf * G8_TILE + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + w_voff[i]),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets: row r (r & 15 == lane & 15), logical piece ks*4 + g -> byte r*128 + ((lp ^ ((r>>1)&7)) << 4)
+    const int g = lane >> 4, li = lane & 15;
+    const int off0 = li * 128 + ((g ^ ((li >> 1) & 7)) << 4);
+    const int d1 = 64 - 2 * (off0 & 64);                          // offset of the second k-step piece: off ^ 64
+    // LDS byte addresses (dynamic LDS starts at offset 0 of the workgroup's allocation: no static __shared__ here)
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem8;
+    const unsigned a_ad0 = lds0 + (wr * 128) * 128 + off0, a_ad1 = a_ad0 + d1;              // + buf*32K + mh*8K + mi*2K
+    const unsigned w_ad0 = lds0 + G8_WOFF + (wc * 64) * 128 + off0, w_ad1 = w_ad0 + d1;     // + buf*32K + nh*4K + nj*2K
+
+    // Fragment reads are raw ds_read_b128 (the compiler does not track them): every consumer is preceded by an
+    // explicit counted s_waitcnt lgkmcnt(n) that names the fragments as operands (G8_WAIT_*).
+    half8_t A0[4][2], A1[4][2], X[2][2], Y[2][2];
+#define G8_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define G8_RD_A(a, BUF, MH)                                                                     \
+    do {                                                                                        \
+        G8_DSR(a[0][0], a_ad0, (BUF) * G8_TILE + (MH) * 8192 + 0 * 2048);                       \
+        G8_DSR(a[0][1], a_ad1, (BUF) * G8_TILE + (MH) * 8192 + 0 * 2048);                       \
+        G8_DSR(a[1][0], a_ad0, (BUF) * G8_TILE + (MH) * 8192 + 1 * 2048);                       \
+        G8_DSR(a[1][1], a_ad1, (BUF) * G8_TILE + (MH) * 8192 + 1 * 2048);                       \
+        G8_DSR(a[2][0], a_ad0, (BUF) * G8_TILE + (MH) * 8192 + 2 * 2048);                       \
+        G8_DSR(a[2][1], a_ad1, (BUF) * G8_TILE + (MH) * 8192 + 2 * 2048);                       \
+        G8_DSR(a[3][0], a_ad0, (BUF) * G8_TILE + (MH) * 8192 + 3 * 2048);                       \
+        G8_DSR(a[3][1], a_ad1, (BUF) * G8_TILE + (MH) * 8192 + 3 * 2048);                       \
+    } while (0)
+#define G8_RD_W(b, BUF, NH)                                                                     \
+    do {                                                                                        \
+        G8_DSR(b[0][0], w_ad0, (BUF) * G8_TILE + (NH) * 4096 + 0 * 2048);                       \
+        G8_DSR(b[0][1], w_ad1, (BUF) * G8_TILE + (NH) * 4096 + 0 * 2048);                       \
+        G8_DSR(b[1][0], w_ad0, (BUF) * G8_TILE + (NH) * 4096 + 1 * 2048);                       \
+        G8_DSR(b[1][1], w_ad1, (BUF) * G8_TILE + (NH) * 4096 + 1 * 2048);                       \
+    } while (0)
+// wait until at most n LDS reads are outstanding; the fragments about to be consumed are tied to the wait
+#define G8_WAIT(n, a, b)                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                      \
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]),      \
+                   "+v"(a[3][0]), "+v"(a[3][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1])       \
+                 :: "memory")
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+
+    const int nk = p.K / G8_BK;                     // even, >= 2 (host)
+    constexpr bool no_dma = ABL & 1, no_rd = ABL & 2, no_epi = ABL & 4;   // experiment instantiations (CVA_GEMM_DBG), ABL = 0 in production
+
+    // ---- prologue: E <- tile 0, O <- tile 1; first quadrant operands
+    stage_a(0, 0);
+    stage_w(0, 0);
+    stage_w(1, 1);
+    stage_a(1, 1);
+    G8_VMCNT(8);                                    // E has landed (O may still be in flight)
+    G8_BAR();
+    if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }
+    if (wr == 1) G8_BAR();                          // stagger the second wave group by one barrier
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        const bool more = kt + 2 < nk;              // block-uniform
+        // ---- phase 1
+        if (!no_rd) G8_RD_W(Y, 0, 1);
+        G8_BAR(); G8_MMQ(4, A0, X, 0, 0); G8_BAR();
+        // ---- phase 2
+        if (!no_rd) G8_RD_A(A1, 0, 1);
+        G8_BAR(); G8_MMQ(8, A0, Y, 0, 1); G8_BAR();
+        // ---- phase 3
+        if (more && !no_dma) { stage_w(0, kt + 2); G8_VMCNT(4); } else { G8_VMCNT(0); }
+        G8_BAR(); G8_MMQ(0, A1, Y, 1, 1); G8_BAR();
+        // ---- phase 4
+        if (!no_rd) { G8_RD_A(A0, 1, 0); G8_RD_W(Y, 1, 0); }
+        if (more && !no_dma) stage_a(0, kt + 2);
+        G8_BAR(); G8_MMQ(12, A1, X, 1, 0); G8_BAR();
+        // ---- phase 5
+        if (!no_rd) G8_RD_W(X, 1, 1);
+        G8_BAR(); G8_MMQ(4, A0, Y, 0, 0); G8_BAR();
+        // ---- phase 6
+        if (!no_rd) G8_RD_A(A1, 1, 1);
+        G8_BAR(); G8_MMQ(8, A0, X, 0, 1); G8_BAR();
+        // ---- phase 7
+        if (more && !no_dma) { stage_w(1, kt + 3); G8_VMCNT(4); } else { G8_VMCNT(0); }
+        G8_BAR(); G8_MMQ(0, A1, X, 1, 1); G8_BAR();
+        // ---- phase 8
+        if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }     // (after the last tile: a harmless read of stale data)
+        if (more && !no_dma) stage_a(1, kt + 3);
+        G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (wr == 0) G8_BAR();                          // re-align the wave groups: every LDS read has retired
+
+    if (no_epi) {      // experiment: keep the accumulators live, one store per lane
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        reinterpret_cast<half_t*>(p.out)[(long)(m0 + wr * 128 + (lane >> 4)) * p.ldc + n0 + wc * 64 + (lane & 15)] = (half_t)t;
+        return;
+    }
+    if (TRANS) {
+        epilogue8_direct<OMODE>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+    } else {
+        float* st = reinterpret_cast<float*>(smem8) + wave * (16 * 68);
+        gemm_epilogue_lds<half_t, OMODE, 8, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, st, lane);
+    }
+}
+
+template <int OMODE, int TRANS, int ABL>
+int launch8(const GemmParams& p, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<OMODE, TRANS, ABL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return (int)hipGetLastError();
+        attr = true;
+    }
+    const int tiles = (p.M / G8_BM) * (p.N / G8_BN);
+    hipLaunchKernelGGL((gemm8_kernel<OMODE, TRANS, ABL>), dim3(tiles), dim3(G8_NT), G8_LDS, stream, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool gemm8_supported(const GemmParams& p, int a_mode, size_t elem_size) {
+    if (elem_size != 2 || a_mode != A_LINEAR || !p.epi_vec) return false;
+    if (p.M % G8_BM || p.N % G8_BN || p.K % (2 * G8_BK) || p.K < 2 * G8_BK) return false;
+    if (((size_t)p.A & 15) || ((size_t)p.W & 15) || (p.lda % 8) || (p.ldw % 8) || p.ldw < p.K) return false;
+    long max_arow = p.M - 1;
+    if (p.a_rpi > 0) max_arow = (long)(p.M - 1) + (long)((p.M - 1) / p.a_rpi) * p.a_extra + p.a_off;
+    if ((max_arow + 1) * (long)p.lda * 2 >= (1L << 31) || (long)p.N * p.ldw * 2 >= (1L << 31)) return false;
+    if (p.out_mode == OUT_QKV && (p.D % G8_BN || p.hd % 16 || p.N != 3 * p.D || p.n_off)) return false;
+    return true;
+}
+
+int launch_gemm8(const GemmParams& p, hipStream_t stream) {
+    if (p.out_mode == OUT_LINEAR) {
+        switch (p.dbg & 7) {
+            case 4: return launch8<OUT_LINEAR, 1, 4>(p, stream);
+            case 7: return launch8<OUT_LINEAR, 1, 7>(p, stream);
+            case 1: return launch8<OUT_LINEAR, 1, 1>(p, stream);
+            case 2: return launch8<OUT_LINEAR, 1, 2>(p, stream);
+            case 3: return launch8<OUT_LINEAR, 1, 3>(p, stream);
+            case 5: return launch8<OUT_LINEAR, 0, 0>(p, stream);      // LDS-staged epilogue, for A/B
+            default: return launch8<OUT_LINEAR, 1, 0>(p, stream);
+        }
+    }
+    if (p.out_mode == OUT_QKV) {
+        // q, k columns: transposed accumulators + direct stores; v columns: V^T is contiguous along tokens,
+        // which is the natural (untransposed) fragment orientation -> LDS-staged epilogue.
+        GemmParams qk = p, v = p;
+        qk.N = 2 * p.D;
+        v.N = p.N - 2 * p.D;
+        v.W = reinterpret_cast<const half_t*>(p.W) + (size_t)2 * p.D * p.ldw;
+        v.bias = p.bias ? p.bias + 2 * p.D : nullptr;
+        v.n_off = p.n_off + 2 * p.D;
+        int e = launch8<OUT_QKV, 1, 0>(qk, stream);
+        if (e) return e;
+        return launch8<OUT_QKV, 0, 0>(v, stream);
+    }
+    return launch8<OUT_CONVT, 0, 0>(p, stream);
+}
+
+}  // namespace cva

@@ -33,8 +33,21 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    ref = (A[:256].float() @ W.float().t())
-    err = float((out[:256].float() - ref).abs().max())
+    # full-matrix check (in row blocks) + race screen: repeated launches must reproduce the first result bit for bit
+    err = 0.0
+    for r0 in range(0, M, 4096):
+        ref = A[r0:r0 + 4096].float() @ W.float().t()
+        err = max(err, float((out[r0:r0 + 4096].float() - ref).abs().max()))
+    first = out.clone()
+    nrace = int(os.environ.get("RACE", "5"))
+    bad = 0
+    for _ in range(nrace):
+        out.zero_()
+        lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, 0, None)
+        torch.cuda.synchronize()
+        bad += int((out != first).sum().item())
+    if bad:
+        print(f"RACE: {bad} mismatching elements over {nrace} repeats")
     print(f"CVA_GEMM={os.environ.get('CVA_GEMM', '1')} M={M} N={N} K={K}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s  maxerr {err:.3e}")
 
 
