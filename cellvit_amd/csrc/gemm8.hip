@@ -186,6 +186,88 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
     }
 }
 
+
+// Direct V^T epilogue for the v columns of the fused qkv projection.  Those tiles run the SAME transposed
+// kernel with the operands exchanged (C^T = W_v . X^T: the "A" tile holds 256 W rows, the permuted "W" tile 256
+// token rows), so lane (g, li) holds, for column n = i*16 + li of the wave block, the 16 CONSECUTIVE tokens
+// g*16 .. g*16+15.  V^T is [S*heads, hd, Lp], contiguous along the token position: global attention gets
+// 16-byte stores, window-partitioned layers 4-byte stores of token pairs (a pair never straddles a window when
+// the window size and the grid width are even).
+__device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8][4], const int nrow0, const int mcol0,
+                                             const int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    const int mb = mcol0 + g * 16;                               // first of this lane's 16 tokens
+    half_t* vt = reinterpret_cast<half_t*>(p.vt_out);
+    const int b0 = mb / p.ntok, t0 = mb - b0 * p.ntok;
+    const bool fast = p.win == 0 && t0 + 15 < p.ntok && (t0 & 7) == 0;
+    // token -> offset inside one (s, h, d) row of V^T, for the 8 token pairs (window mode)
+    long poff[8]; bool pair_ok[8];
+    if (!fast) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            long o[2];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int mm = mb + 2 * u + w;
+                const int b = mm / p.ntok, t = mm - b * p.ntok;
+                int s_ = b, pos = t;
+                if (p.win > 0) {
+                    const int gy = t / p.gw, gx = t - gy * p.gw;
+                    const int wy = gy / p.win, wx = gx / p.win;
+                    s_ = (b * p.nwy + wy) * p.nwx + wx;
+                    pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
+                }
+                o[w] = (long)s_ * p.heads * p.hd * p.Lp + pos;
+            }
+            poff[u] = o[0];
+            pair_ok[u] = (o[1] == o[0] + 1) && ((o[0] & 1) == 0);
+            if (!pair_ok[u]) poff[u] = -1 - (long)(mb + 2 * u);   // resolved per element below (rare: odd geometry)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = nrow0 + i * 16 + li;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+        const int c = n + p.n_off - 2 * p.D;
+        const int h = c / p.hd, d = c - h * p.hd;
+        const long rowoff = ((long)h * p.hd + d) * p.Lp;
+        if (fast) {
+            half_t* dst = vt + (long)b0 * p.heads * p.hd * p.Lp + rowoff + t0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                half8_t w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = (half_t)(acc[i][q * 2 + (e >> 2)][e & 3] + bv);
+                *reinterpret_cast<half8_t*>(dst + q * 8) = w;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const half_t v0 = (half_t)(acc[i][u >> 1][(u & 1) * 2] + bv), v1 = (half_t)(acc[i][u >> 1][(u & 1) * 2 + 1] + bv);
+                if (pair_ok[u]) {
+                    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+                    const half2_t w = {v0, v1};
+                    *reinterpret_cast<half2_t*>(vt + poff[u] + rowoff) = w;
+                } else {
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const int mm = (int)(-1 - poff[u]) + w;
+                        const int b = mm / p.ntok, t = mm - b * p.ntok;
+                        int s_ = b, pos = t;
+                        if (p.win > 0) {
+                            const int gy = t / p.gw, gx = t - gy * p.gw;
+                            const int wy = gy / p.win, wx = gx / p.win;
+                            s_ = (b * p.nwy + wy) * p.nwx + wx;
+                            pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
+                        }
+                        vt[(long)s_ * p.heads * p.hd * p.Lp + rowoff + pos] = w ? v1 : v0;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int OMODE, int TRANS, int ABL>
 __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
@@ -198,24 +280,34 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
     const int m0 = tm * G8_BM, n0 = tn * G8_BN;
 
-    // ---- DMA source offsets (bytes, 32-bit; host guarantees they fit) of the 4 A rows and 4 W rows this lane stages
+    // v columns of the fused qkv projection: exchange the operands (see epilogue8_vt); block-uniform
+    const bool swap = OMODE == OUT_QKV && TRANS == 1 && (n0 + p.n_off) >= 2 * p.D;
+
+    // ---- DMA source offsets (bytes, 32-bit; host guarantees they fit) of the 4 "A"-tile rows and 4 "W"-tile rows this lane stages
     const int lrow = lane >> 3, lpc = lane & 7;
+    auto a_bytes = [&](int m) {       // byte offset of activation row m
+        long r = m;
+        if (p.a_rpi > 0) r = (long)m + (long)(m / p.a_rpi) * p.a_extra + p.a_off;
+        return (unsigned)(r * (long)p.lda * 2);
+    };
     unsigned a_voff[4], w_voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = wave * 32 + i * 8 + lrow;
         const int lp = lpc ^ ((row >> 1) & 7);
-        const int m = m0 + row;
-        long r = m;
-        if (p.a_rpi > 0) r = (long)m + (long)(m / p.a_rpi) * p.a_extra + p.a_off;
-        a_voff[i] = (unsigned)((r * (long)p.lda + lp * 8) * 2);
-        // TRANS: LDS row wc*64 + j*16 + g*4 + r holds W row wc*64 + g*16 + j*4 + r, so that a lane's 16 accumulator
-        // values per output row are 16 consecutive columns (see epilogue8_direct)
-        const int wrow = TRANS ? ((row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3)) : row;
-        w_voff[i] = (unsigned)(((long)(n0 + wrow) * p.ldw + lp * 8) * 2);
+        // TRANS: LDS row wc*64 + j*16 + g*4 + r of the "W" tile holds source row wc*64 + g*16 + j*4 + r, so that a lane's
+        // 16 accumulator values per output row are 16 consecutive columns (see epilogue8_direct)
+        const int prow = TRANS == 1 ? ((row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3)) : row;
+        if (!swap) {
+            a_voff[i] = a_bytes(m0 + row) + lp * 16;
+            w_voff[i] = (unsigned)((long)(n0 + prow) * p.ldw * 2) + lp * 16;
+        } else {
+            a_voff[i] = (unsigned)((long)(n0 + row) * p.ldw * 2) + lp * 16;
+            w_voff[i] = a_bytes(m0 + prow) + lp * 16;
+        }
     }
-    const unsigned char* __restrict__ Ab = reinterpret_cast<const unsigned char*>(p.A);
-    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.W);
+    const unsigned char* __restrict__ Ab = reinterpret_cast<const unsigned char*>(swap ? p.W : p.A);
+    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(swap ? p.A : p.W);
 
     auto stage_a = [&](int buf, int kt) {
         const unsigned char* base = uniform_ptr(Ab + (long)kt * (G8_BK * 2));
@@ -333,7 +425,8 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         return;
     }
     if (TRANS) {
-        epilogue8_direct<OMODE>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+        if (swap) epilogue8_vt(p, acc, n0 + wr * 128, m0 + wc * 64, lane);
+        else epilogue8_direct<OMODE>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
     } else {
         float* st = reinterpret_cast<float*>(smem8) + wave * (16 * 68);
         gemm_epilogue_lds<half_t, OMODE, 8, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, st, lane);
@@ -379,19 +472,7 @@ int launch_gemm8(const GemmParams& p, hipStream_t stream) {
             default: return launch8<OUT_LINEAR, 1, 0>(p, stream);
         }
     }
-    if (p.out_mode == OUT_QKV) {
-        // q, k columns: transposed accumulators + direct stores; v columns: V^T is contiguous along tokens,
-        // which is the natural (untransposed) fragment orientation -> LDS-staged epilogue.
-        GemmParams qk = p, v = p;
-        qk.N = 2 * p.D;
-        v.N = p.N - 2 * p.D;
-        v.W = reinterpret_cast<const half_t*>(p.W) + (size_t)2 * p.D * p.ldw;
-        v.bias = p.bias ? p.bias + 2 * p.D : nullptr;
-        v.n_off = p.n_off + 2 * p.D;
-        int e = launch8<OUT_QKV, 1, 0>(qk, stream);
-        if (e) return e;
-        return launch8<OUT_QKV, 0, 0>(v, stream);
-    }
+    if (p.out_mode == OUT_QKV) return launch8<OUT_QKV, 1, 0>(p, stream);
     return launch8<OUT_CONVT, 0, 0>(p, stream);
 }
 
