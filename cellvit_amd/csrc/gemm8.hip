@@ -45,7 +45,8 @@ using namespace epi;
 constexpr int G8_BM = 256, G8_BN = 256, G8_BK = 64, G8_NT = 512;
 constexpr int G8_TILE = 256 * 128;          // bytes of one A or W tile (256 rows x 128 B)
 constexpr int G8_WOFF = 2 * G8_TILE;        // LDS layout: [E.A][O.A][E.W][O.W] -> buffer select = +32 KiB immediate offset
-constexpr int G8_LDS = 4 * G8_TILE;
+constexpr int G8_BIAS = 4 * G8_TILE;       // two 1-KiB bias slots (256 floats each, alternating per output tile)
+constexpr int G8_LDS = 4 * G8_TILE + 2048;
 
 #define G8_BAR()                                   \
     do {                                           \
@@ -102,17 +103,10 @@ __device__ __forceinline__ float gelu_as(float x) {
 // m = i*16 + li of the wave block, the 16 CONSECUTIVE columns g*16 .. g*16+15 — the W rows are permuted at DMA
 // time to make them consecutive).  No LDS: bias / activation / residual on registers, 16-byte stores.
 template <int OMODE>
-__device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&acc)[8][4], const int mrow0, const int ncol0,
-                                                 const int lane) {
+__device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&acc)[8][4], const float (&bv)[16],
+                                                 const int mrow0, const int ncol0, const int lane) {
     const int g = lane >> 4, li = lane & 15;
     const int n = ncol0 + g * 16;
-    float bv[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 b4 = (f32x4)(0.f);
-        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + n + q * 4);
-        bv[q * 4 + 0] = b4[0]; bv[q * 4 + 1] = b4[1]; bv[q * 4 + 2] = b4[2]; bv[q * 4 + 3] = b4[3];
-    }
     half_t* qk = nullptr;
     long col_term = 0;
     if (OMODE == OUT_QKV) {
@@ -193,8 +187,8 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
 // g*16 .. g*16+15.  V^T is [S*heads, hd, Lp], contiguous along the token position: global attention gets
 // 16-byte stores, window-partitioned layers 4-byte stores of token pairs (a pair never straddles a window when
 // the window size and the grid width are even).
-__device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8][4], const int nrow0, const int mcol0,
-                                             const int lane) {
+__device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8][4], const float (&bvt)[16],
+                                             const int nrow0, const int mcol0, const int lane) {
     const int g = lane >> 4, li = lane & 15;
     const int mb = mcol0 + g * 16;                               // first of this lane's 16 tokens
     half_t* vt = reinterpret_cast<half_t*>(p.vt_out);
@@ -227,7 +221,7 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int n = nrow0 + i * 16 + li;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const float bv = bvt[i];
         const int c = n + p.n_off - 2 * p.D;
         const int h = c / p.hd, d = c - h * p.hd;
         const long rowoff = ((long)h * p.hd + d) * p.Lp;
@@ -275,15 +269,10 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int tiles_n = p.N / G8_BN, tiles_m = p.M / G8_BM;
-    int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * G8_BM, n0 = tn * G8_BN;
+    const int tiles_n = p.N / G8_BN, tiles_m = p.M / G8_BM, ntiles = tiles_m * tiles_n;
 
-    // v columns of the fused qkv projection: exchange the operands (see epilogue8_vt); block-uniform
-    const bool swap = OMODE == OUT_QKV && TRANS == 1 && (n0 + p.n_off) >= 2 * p.D;
-
-    // ---- DMA source offsets (bytes, 32-bit; host guarantees they fit) of the 4 "A"-tile rows and 4 "W"-tile rows this lane stages
+    // ---- per-tile state.  (m0, n0, swap) of the tile being computed / stored; the DMA row offsets and bases below
+    // always describe the tile whose DMA is issued NEXT (they are advanced to tile t+1 before tile t's epilogue).
     const int lrow = lane >> 3, lpc = lane & 7;
     auto a_bytes = [&](int m) {       // byte offset of activation row m
         long r = m;
@@ -291,47 +280,57 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         return (unsigned)(r * (long)p.lda * 2);
     };
     unsigned a_voff[4], w_voff[4];
+    const unsigned char* Ab;
+    const unsigned char* Wb;
+    auto tile_setup = [&](int tile, int& m0, int& n0, bool& swap) {
+        int tm, tn;
+        tile_coords(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
+        m0 = tm * G8_BM; n0 = tn * G8_BN;
+        // v columns of the fused qkv projection: exchange the operands (see epilogue8_vt); block-uniform
+        swap = OMODE == OUT_QKV && TRANS == 1 && (n0 + p.n_off) >= 2 * p.D;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + lrow;
-        const int lp = lpc ^ ((row >> 1) & 7);
-        // TRANS: LDS row wc*64 + j*16 + g*4 + r of the "W" tile holds source row wc*64 + g*16 + j*4 + r, so that a lane's
-        // 16 accumulator values per output row are 16 consecutive columns (see epilogue8_direct)
-        const int prow = TRANS == 1 ? ((row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3)) : row;
-        if (!swap) {
-            a_voff[i] = a_bytes(m0 + row) + lp * 16;
-            w_voff[i] = (unsigned)((long)(n0 + prow) * p.ldw * 2) + lp * 16;
-        } else {
-            a_voff[i] = (unsigned)((long)(n0 + row) * p.ldw * 2) + lp * 16;
-            w_voff[i] = a_bytes(m0 + prow) + lp * 16;
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + lrow;
+            const int lp = lpc ^ ((row >> 1) & 7);
+            // TRANS: LDS row wc*64 + j*16 + g*4 + r of the "W" tile holds source row wc*64 + g*16 + j*4 + r, so that a
+            // lane's 16 accumulator values per output row are 16 consecutive columns (see epilogue8_direct)
+            const int prow = TRANS == 1 ? ((row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3)) : row;
+            if (!swap) {
+                a_voff[i] = a_bytes(m0 + row) + lp * 16;
+                w_voff[i] = (unsigned)((long)(n0 + prow) * p.ldw * 2) + lp * 16;
+            } else {
+                a_voff[i] = (unsigned)((long)(n0 + row) * p.ldw * 2) + lp * 16;
+                w_voff[i] = a_bytes(m0 + prow) + lp * 16;
+            }
         }
-    }
-    const unsigned char* __restrict__ Ab = reinterpret_cast<const unsigned char*>(swap ? p.W : p.A);
-    const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(swap ? p.A : p.W);
+        Ab = reinterpret_cast<const unsigned char*>(swap ? p.W : p.A);
+        Wb = reinterpret_cast<const unsigned char*>(swap ? p.A : p.W);
+    };
 
+    // Direct-to-LDS DMA, written as inline asm to pin the `v_off, s[base:base+1]` addressing form (the builtin lets the
+    // optimiser keep per-lane 64-bit pointers in VGPRs: 16 registers this kernel does not have).  M0 = LDS byte address
+    // of the 1-KiB destination (wave-uniform); no other code in this kernel depends on M0.
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem8;
+#define G8_DMA(voff, base, ldsaddr)                                                                         \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), \
+                 "s"(ldsaddr) : "memory")
     auto stage_a = [&](int buf, int kt) {
         const unsigned char* base = uniform_ptr(Ab + (long)kt * (G8_BK * 2));
-        unsigned char* dst = smem8 + buf * G8_TILE + wave * 4096;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G8_TILE + wave * 4096);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + a_voff[i]),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) G8_DMA(a_voff[i], base, dst + i * 1024);
     };
     auto stage_w = [&](int buf, int kt) {
         const unsigned char* base = uniform_ptr(Wb + (long)kt * (G8_BK * 2));
-        unsigned char* dst = smem8 + G8_WOFF + buf * G8_TILE + wave * 4096;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + G8_WOFF + buf * G8_TILE + wave * 4096);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + w_voff[i]),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) G8_DMA(w_voff[i], base, dst + i * 1024);
     };
 
     // ---- fragment read offsets: row r (r & 15 == lane & 15), logical piece ks*4 + g -> byte r*128 + ((lp ^ ((r>>1)&7)) << 4)
     const int g = lane >> 4, li = lane & 15;
     const int off0 = li * 128 + ((g ^ ((li >> 1) & 7)) << 4);
     const int d1 = 64 - 2 * (off0 & 64);                          // offset of the second k-step piece: off ^ 64
-    // LDS byte addresses (dynamic LDS starts at offset 0 of the workgroup's allocation: no static __shared__ here)
-    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem8;
     const unsigned a_ad0 = lds0 + (wr * 128) * 128 + off0, a_ad1 = a_ad0 + d1;              // + buf*32K + mh*8K + mi*2K
     const unsigned w_ad0 = lds0 + G8_WOFF + (wc * 64) * 128 + off0, w_ad1 = w_ad0 + d1;     // + buf*32K + nh*4K + nj*2K
 
@@ -364,72 +363,127 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
                    "+v"(a[3][0]), "+v"(a[3][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1])       \
                  :: "memory")
 
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
-
     const int nk = p.K / G8_BK;                     // even, >= 2 (host)
     constexpr bool no_dma = ABL & 1, no_rd = ABL & 2, no_epi = ABL & 4;   // experiment instantiations (CVA_GEMM_DBG), ABL = 0 in production
 
-    // ---- prologue: E <- tile 0, O <- tile 1; first quadrant operands
-    stage_a(0, 0);
-    stage_w(0, 0);
-    stage_w(1, 1);
-    stage_a(1, 1);
-    G8_VMCNT(8);                                    // E has landed (O may still be in flight)
-    G8_BAR();
-    if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }
-    if (wr == 1) G8_BAR();                          // stagger the second wave group by one barrier
+    // E <- tile 0, O <- tile 1 of the K loop (16 DMA loads per lane); wave 0 first fetches the tile's 256 bias values
+    // into LDS slot `slot` (the oldest load of the group, so the counted waits below cover it): the epilogue then needs
+    // no VMEM load, which would otherwise have to wait for the whole in-order DMA queue.
+    auto stage_prologue = [&](int n0_, bool swap_, int slot) {
+        if (TRANS && p.bias && wave == 0) {
+            (void)swap_;
+            const unsigned char* src = uniform_ptr(reinterpret_cast<const unsigned char*>(p.bias + n0_));
+            const unsigned boff = lane * 16;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + G8_BIAS + slot * 1024);
+            G8_DMA(boff, src, dst);
+        }
+        stage_a(0, 0);
+        stage_w(0, 0);
+        stage_w(1, 1);
+        stage_a(1, 1);
+    };
 
-    for (int kt = 0; kt < nk; kt += 2) {
-        const bool more = kt + 2 < nk;              // block-uniform
-        // ---- phase 1
-        if (!no_rd) G8_RD_W(Y, 0, 1);
-        G8_BAR(); G8_MMQ(4, A0, X, 0, 0); G8_BAR();
-        // ---- phase 2
-        if (!no_rd) G8_RD_A(A1, 0, 1);
-        G8_BAR(); G8_MMQ(8, A0, Y, 0, 1); G8_BAR();
-        // ---- phase 3
-        if (more && !no_dma) { stage_w(0, kt + 2); G8_VMCNT(4); } else { G8_VMCNT(0); }
-        G8_BAR(); G8_MMQ(0, A1, Y, 1, 1); G8_BAR();
-        // ---- phase 4
-        if (!no_rd) { G8_RD_A(A0, 1, 0); G8_RD_W(Y, 1, 0); }
-        if (more && !no_dma) stage_a(0, kt + 2);
-        G8_BAR(); G8_MMQ(12, A1, X, 1, 0); G8_BAR();
-        // ---- phase 5
-        if (!no_rd) G8_RD_W(X, 1, 1);
-        G8_BAR(); G8_MMQ(4, A0, Y, 0, 0); G8_BAR();
-        // ---- phase 6
-        if (!no_rd) G8_RD_A(A1, 1, 1);
-        G8_BAR(); G8_MMQ(8, A0, X, 0, 1); G8_BAR();
-        // ---- phase 7
-        if (more && !no_dma) { stage_w(1, kt + 3); G8_VMCNT(4); } else { G8_VMCNT(0); }
-        G8_BAR(); G8_MMQ(0, A1, X, 1, 1); G8_BAR();
-        // ---- phase 8
-        if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }     // (after the last tile: a harmless read of stale data)
-        if (more && !no_dma) stage_a(1, kt + 3);
-        G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (wr == 0) G8_BAR();                          // re-align the wave groups: every LDS read has retired
-
-    if (no_epi) {      // experiment: keep the accumulators live, one store per lane
-        float t = 0.f;
+    // ---- persistent loop over output tiles: the DMA of tile t+1's first two K tiles is issued BEFORE tile t's
+    // epilogue, so its latency (and the epilogue's store drain) overlap instead of adding up
+    int m0, n0; bool swap;
+    int tile = blockIdx.x;
+    int slot = 0;
+    tile_setup(tile, m0, n0, swap);
+    stage_prologue(n0, swap, slot);
+    for (; tile < ntiles; tile += gridDim.x, slot ^= 1) {
+        f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        reinterpret_cast<half_t*>(p.out)[(long)(m0 + wr * 128 + (lane >> 4)) * p.ldc + n0 + wc * 64 + (lane & 15)] = (half_t)t;
-        return;
-    }
-    if (TRANS) {
-        if (swap) epilogue8_vt(p, acc, n0 + wr * 128, m0 + wc * 64, lane);
-        else epilogue8_direct<OMODE>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-    } else {
-        float* st = reinterpret_cast<float*>(smem8) + wave * (16 * 68);
-        gemm_epilogue_lds<half_t, OMODE, 8, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, st, lane);
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+
+        G8_VMCNT(8);                                // E has landed (O may still be in flight); older epilogue stores have drained
+        G8_BAR();
+        if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }
+        if (wr == 1) G8_BAR();                      // stagger the second wave group by one barrier
+
+        for (int kt = 0; kt < nk; kt += 2) {
+            const bool more = kt + 2 < nk;          // block-uniform
+            // ---- phase 1
+            if (!no_rd) G8_RD_W(Y, 0, 1);
+            G8_BAR(); G8_MMQ(4, A0, X, 0, 0); G8_BAR();
+            // ---- phase 2
+            if (!no_rd) G8_RD_A(A1, 0, 1);
+            G8_BAR(); G8_MMQ(8, A0, Y, 0, 1); G8_BAR();
+            // ---- phase 3
+            if (more && !no_dma) { stage_w(0, kt + 2); G8_VMCNT(4); } else { G8_VMCNT(0); }
+            G8_BAR(); G8_MMQ(0, A1, Y, 1, 1); G8_BAR();
+            // ---- phase 4
+            if (!no_rd) { G8_RD_A(A0, 1, 0); G8_RD_W(Y, 1, 0); }
+            if (more && !no_dma) stage_a(0, kt + 2);
+            G8_BAR(); G8_MMQ(12, A1, X, 1, 0); G8_BAR();
+            // ---- phase 5
+            if (!no_rd) G8_RD_W(X, 1, 1);
+            G8_BAR(); G8_MMQ(4, A0, Y, 0, 0); G8_BAR();
+            // ---- phase 6
+            if (!no_rd) G8_RD_A(A1, 1, 1);
+            G8_BAR(); G8_MMQ(8, A0, X, 0, 1); G8_BAR();
+            // ---- phase 7
+            if (more && !no_dma) { stage_w(1, kt + 3); G8_VMCNT(4); } else { G8_VMCNT(0); }
+            G8_BAR(); G8_MMQ(0, A1, X, 1, 1); G8_BAR();
+            // ---- phase 8
+            if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }     // (after the last tile: a harmless read of stale data)
+            if (more && !no_dma) stage_a(1, kt + 3);
+            G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (wr == 0) G8_BAR();                      // re-align the wave groups: every LDS read has retired
+
+        const int em0 = m0, en0 = n0; const bool eswap = swap;
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        // bias of this lane's outputs from the tile's LDS slot (staged with the tile's first DMA group)
+        float bv[16];
+        if (TRANS) {
+            const float* bs = reinterpret_cast<const float*>(smem8 + G8_BIAS + slot * 1024);
+            if (!eswap) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 b4 = (f32x4)(0.f);
+                    if (p.bias) b4 = *reinterpret_cast<const f32x4*>(bs + wc * 64 + (lane >> 4) * 16 + q * 4);
+                    bv[q * 4 + 0] = b4[0]; bv[q * 4 + 1] = b4[1]; bv[q * 4 + 2] = b4[2]; bv[q * 4 + 3] = b4[3];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { bv[i] = p.bias ? bs[wr * 128 + i * 16 + (lane & 15)] : 0.f; bv[8 + i] = 0.f; }
+            }
+        }
+        // Epilogues that read a residual issue the next tile's DMA after their last load (VMEM loads retire in order: a
+        // load issued behind the DMA group could only be consumed once the whole group had landed).
+        const bool dma_first = TRANS && has_next && !(OMODE == OUT_LINEAR && p.res) && !(p.dbg & 16);
+        if (dma_first) {                            // direct epilogues do not touch LDS: start the next tile's DMA first
+            tile_setup(tile + gridDim.x, m0, n0, swap);
+            stage_prologue(n0, swap, slot ^ 1);
+        }
+        if (no_epi) {      // experiment: keep the accumulators live, one store per lane
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            reinterpret_cast<half_t*>(p.out)[(long)(em0 + wr * 128 + (lane >> 4)) * p.ldc + en0 + wc * 64 + (lane & 15)] = (half_t)t;
+            if (has_next && !dma_first) { tile_setup(tile + gridDim.x, m0, n0, swap); stage_prologue(n0, swap, slot ^ 1); }
+        } else if (TRANS) {
+            if (eswap) epilogue8_vt(p, acc, bv, en0 + wr * 128, em0 + wc * 64, lane);
+            else epilogue8_direct<OMODE>(p, acc, bv, em0 + wr * 128, en0 + wc * 64, lane);
+            if (has_next && !dma_first) {
+                tile_setup(tile + gridDim.x, m0, n0, swap);
+                stage_prologue(n0, swap, slot ^ 1);
+            }
+        } else {
+            float* st = reinterpret_cast<float*>(smem8) + wave * (16 * 68);
+            gemm_epilogue_lds<half_t, OMODE, 8, 4>(p, acc, em0 + wr * 128, en0 + wc * 64, st, lane);
+            if (has_next) {                         // staged epilogue used LDS: fence it before the next tile's DMA
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                G8_BAR();
+                tile_setup(tile + gridDim.x, m0, n0, swap);
+                stage_prologue(n0, swap, slot ^ 1);
+            }
+        }
     }
 }
 
@@ -442,8 +496,15 @@ int launch8(const GemmParams& p, hipStream_t stream) {
             return (int)hipGetLastError();
         attr = true;
     }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+    }
     const int tiles = (p.M / G8_BM) * (p.N / G8_BN);
-    hipLaunchKernelGGL((gemm8_kernel<OMODE, TRANS, ABL>), dim3(tiles), dim3(G8_NT), G8_LDS, stream, p);
+    const int grid = (tiles < n_cu || (p.dbg & 32)) ? tiles : n_cu;   // persistent: one workgroup per CU walks tiles grid-stride
+    hipLaunchKernelGGL((gemm8_kernel<OMODE, TRANS, ABL>), dim3(grid), dim3(G8_NT), G8_LDS, stream, p);
     return (int)hipGetLastError();
 }
 
