@@ -32,7 +32,9 @@
 //        E: wait in 7, read from 8).  vmcnt never drops to 0 inside the loop: one tile of DMA (4 loads per
 //        lane) is always left in flight across the barriers.
 // (Measured: mixing ordinary VGPR loads, e.g. an L2 prefetch touch, into the same vmcnt stream breaks the counted
-//  waits — LDS-DMA loads and VGPR loads do not retire in order with respect to each other.)
+//  waits — LDS-DMA loads and VGPR loads do not retire in order with respect to each other.  Giving the DMA to one
+//  wave group and L2-prefetch touches to the other is correct but 4-8 % SLOWER than no prefetch: the stalls at the
+//  counted waits are not HBM misses that a touch could turn into L2 hits.)
 #include "gemm.h"
 #include "gemm_epilogue.h"
 
