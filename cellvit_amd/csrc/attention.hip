@@ -246,18 +246,27 @@ __global__ void pad_kv_kernel(const PadKVParams p) {
     const int s = blockIdx.y;
     const int npad = p.L - vy * vx;
     const long total = (long)npad * p.D;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % p.D);
-        int k = (int)(i / p.D);                      // k-th padded position of the window, row-major
+    const int head_pad = vy * (p.win - vx);
+    auto pad_pos = [&](int k) {                      // k-th padded position of the window, row-major
         // rows 0..vy-1 have (win - vx) padded columns each, rows vy.. are fully padded
         int py, px;
-        const int head_pad = vy * (p.win - vx);
         if (k < head_pad) { py = k / (p.win - vx); px = vx + (k - py * (p.win - vx)); }
         else { k -= head_pad; py = vy + k / p.win; px = k - (k / p.win) * p.win; }
-        const int pos = py * p.win + px;
+        return py * p.win + px;
+    };
+    // K [s, h, pos, d]: channel fastest (contiguous runs of hd elements per position)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % p.D);
+        const int pos = pad_pos((int)(i / p.D));
         const int h = c / p.hd, d = c - h * p.hd;
         reinterpret_cast<T*>(p.K)[(((long)s * p.heads + h) * p.L + pos) * p.hd + d] =
             Traits<T>::from_float(p.qkv_bias[p.D + c]);
+    }
+    // V^T [s, h, d, pos]: position fastest (the padded positions of one row are a few contiguous runs)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i / npad);
+        const int pos = pad_pos((int)(i - (long)c * npad));
+        const int h = c / p.hd, d = c - h * p.hd;
         reinterpret_cast<T*>(p.Vt)[(((long)s * p.heads + h) * p.hd + d) * p.Lp + pos] =
             Traits<T>::from_float(p.qkv_bias[2 * p.D + c]);
     }

@@ -95,12 +95,64 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
         }
     }
 
+    // K / V^T tiles are fetched one tile ahead into registers (issue early, write to LDS after the barrier):
+    // the global-memory latency of tile kt+1 hides behind the MFMAs of tile kt.
+    constexpr int KPPR = HD / PE, VPPR = KT / PE;
+    constexpr int KN = (KT * KPPR + NT - 1) / NT, VN = (HD * VPPR + NT - 1) / NT;
+    Piece kreg[KN], vreg[VN];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < KN; ++u) {
+            const int i = tid + u * NT;
+            const int r = i / KPPR, c = i - r * KPPR;
+            const int key = kt * KT + r;
+            kreg[u] = (i < KT * KPPR && key < p.nk) ? load_piece(Kg + (long)key * HD + c * PE) : zero_piece();
+        }
+#pragma unroll
+        for (int u = 0; u < VN; ++u) {
+            const int i = tid + u * NT;
+            const int d = i / VPPR, c = i - d * VPPR;
+            const int key0 = kt * KT + c * PE;
+            Piece v = zero_piece();
+            if (i < HD * VPPR) {
+                v = load_piece(Vg + (long)d * p.Lp + key0);
+                if (key0 + PE > p.nk) {                 // never let stale bytes past the last key meet P = 0
+                    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+                    for (int j = 0; j < PE; ++j) if (key0 + j >= p.nk) e[j] = TR::from_float(0.f);
+                }
+            }
+            vreg[u] = v;
+        }
+    };
+    fetch(0);                                          // in flight during the rel-pos prologue
+
     // ---- decomposed rel-pos: relcat[q][kh] = q·tab_h[qy-kh+KH-1] / scale ; relcat[q][KH+kw] likewise ----
     const float inv_scale = 1.0f / p.scale;
     if (BIAS != 0) {
         constexpr int RCP = (BIAS == 1) ? PE1 : RC2;
         T* myrc = Rc + (wave * QW) * RCP;
         for (int i = lane; i < QW * RCP; i += 64) myrc[i] = TR::from_float(0.f);
+        // BIAS 1 (2*K - 1 <= 32 table rows): both tables are staged once per block, coalesced, into LDS as T-typed rows of
+        // pitch PK (zero padded to 32 rows x HDP columns; aliased onto the K / V^T tile area, which is idle until the key
+        // loop), so that the table fragments below are single 16-byte LDS reads instead of 8 scattered global loads.
+        T* Ts = Ks;
+        const bool STAGED = (BIAS == 1) && (2 * 32 * PK <= KT * PK + HD * PV) && (HD % 4 == 0) && p.KH <= 16 && p.KW <= 16;   // block-uniform
+        if (STAGED) {
+            for (int i = tid; i < 2 * 32 * (PK / PE); i += NT) store_piece(Ts + i * PE, zero_piece());
+            __syncthreads();
+            const int njh = 2 * p.KH - 1, njw = 2 * p.KW - 1;
+            const int nq = (njh + njw) * (HD / 4);
+            for (int i = tid; i < nq; i += NT) {
+                const int row = i / (HD / 4), c4 = i - row * (HD / 4);
+                const bool isw = row >= njh;
+                const float* src = (isw ? p.tab_w + (long)(row - njh) * HD : p.tab_h + (long)row * HD) + c4 * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                T* dst = Ts + ((isw ? 32 + row - njh : row)) * PK + c4 * 4;
+                dst[0] = TR::from_float(v[0]); dst[1] = TR::from_float(v[1]); dst[2] = TR::from_float(v[2]); dst[3] = TR::from_float(v[3]);
+            }
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int tbl = 0; tbl < 2; ++tbl) {
             const float* __restrict__ tab = tbl == 0 ? p.tab_h : p.tab_w;
@@ -115,7 +167,9 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
                 for (int ks = 0; ks < NKS; ++ks) {
                     const int d0 = ks * 32 + g * 8;
                     tf[ks] = TR::zero_frag();
-                    if (j < nj && d0 < HD) {
+                    if (STAGED) {
+                        tf[ks] = TR::load_frag(Ts + (tbl * 32 + j) * PK + d0);
+                    } else if (j < nj && d0 < HD) {
                         const float* src = tab + (long)j * HD + d0;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) set_frag<T>(tf[ks], e, src[e]);
@@ -172,40 +226,9 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
         for (int n = 0; n < ND; ++n) o[qb][n] = (f32x4)(0.f);
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
-    // K / V^T tiles are fetched one tile ahead into registers (issue early, write to LDS after the barrier):
-    // the global-memory latency of tile kt+1 hides behind the MFMAs of tile kt.
-    constexpr int KPPR = HD / PE, VPPR = KT / PE;
-    constexpr int KN = (KT * KPPR + NT - 1) / NT, VN = (HD * VPPR + NT - 1) / NT;
-    Piece kreg[KN], vreg[VN];
-    auto fetch = [&](int kt) {
-#pragma unroll
-        for (int u = 0; u < KN; ++u) {
-            const int i = tid + u * NT;
-            const int r = i / KPPR, c = i - r * KPPR;
-            const int key = kt * KT + r;
-            kreg[u] = (i < KT * KPPR && key < p.nk) ? load_piece(Kg + (long)key * HD + c * PE) : zero_piece();
-        }
-#pragma unroll
-        for (int u = 0; u < VN; ++u) {
-            const int i = tid + u * NT;
-            const int d = i / VPPR, c = i - d * VPPR;
-            const int key0 = kt * KT + c * PE;
-            Piece v = zero_piece();
-            if (i < HD * VPPR) {
-                v = load_piece(Vg + (long)d * p.Lp + key0);
-                if (key0 + PE > p.nk) {                 // never let stale bytes past the last key meet P = 0
-                    T* e = reinterpret_cast<T*>(&v);
-#pragma unroll
-                    for (int j = 0; j < PE; ++j) if (key0 + j >= p.nk) e[j] = TR::from_float(0.f);
-                }
-            }
-            vreg[u] = v;
-        }
-    };
     const bool wave_active = q0 < p.L;                 // waves whose 32 queries are all padding only help staging
 
     const int ntiles = (p.nk + KT - 1) / KT;
-    fetch(0);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
 #pragma unroll
