@@ -23,6 +23,8 @@ struct AttnParams {
     // output row mapping (inverse of the QKV scatter)
     int ntok;               // tokens per image
     int win, gw, gh, nwx, nwy;
+    void* win_prep;         // >= 32 KiB device scratch for attention_win.hip (rel-pos operands of the layer), or null
+    int dbg;                // experiment switches (attention_win.hip, CVA_ATTNW_DBG)
 };
 
 struct RelPosParams {
@@ -42,6 +44,8 @@ struct PadKVParams {        // window mode: keys/values of zero-padded tokens ar
 template <typename T> int launch_attention(const AttnParams& p, hipStream_t stream);
 // v2 (attention2.hip): fused rel-pos; returns -1 when the geometry is not covered (caller uses v1 + launch_relpos)
 template <typename T> int launch_attention2(const AttnParams& p, hipStream_t stream);
+// attention_win.hip: single-pass kernel for <= 208 keys (SAM windows), fp16 only; -1 when not covered
+int launch_attention_win(const AttnParams& p, hipStream_t stream);
 template <typename T> int launch_relpos(const RelPosParams& p, hipStream_t stream);
 template <typename T> int launch_pad_kv(const PadKVParams& p, hipStream_t stream);
 
