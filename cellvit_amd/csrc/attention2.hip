@@ -69,8 +69,13 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int q0 = blockIdx.x * QT + wave * QW;         // first query of this wave
-    const int sh = blockIdx.y;
+    // XCD-aware remap: workgroups are dealt round-robin to the 8 XCDs in launch order; give every XCD a contiguous range
+    // of (sequence, head) pairs so that all query blocks of one head share that XCD's L2 copy of K / V^T
+    // (measured before: K / V fetched 8x from the fabric by the global blocks, FETCH_SIZE 1.37 GB vs 0.25 GB algorithmic)
+    const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int qblk = lin % gridDim.x;
+    const int q0 = qblk * QT + wave * QW;               // first query of this wave
+    const int sh = lin / gridDim.x;
 
     const T* __restrict__ Qg = reinterpret_cast<const T*>(p.Q) + (long)sh * p.L * HD;
     const T* __restrict__ Kg = reinterpret_cast<const T*>(p.K) + (long)sh * p.L * HD;

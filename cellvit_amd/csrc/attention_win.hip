@@ -52,8 +52,10 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
     if (p.dbg & 8) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int q0 = blockIdx.x * WQT + wave * WQW;
-    const int sh = blockIdx.y;
+    // XCD-aware remap (see attention2.hip): both query halves of a (window, head) run on the same XCD
+    const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int q0 = (lin % gridDim.x) * WQT + wave * WQW;
+    const int sh = lin / gridDim.x;
 
     const half_t* __restrict__ Qg = reinterpret_cast<const half_t*>(p.Q) + (long)sh * p.L * HD;
     const half_t* __restrict__ Kg = reinterpret_cast<const half_t*>(p.K) + (long)sh * p.L * HD;

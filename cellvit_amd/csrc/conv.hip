@@ -46,11 +46,16 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
     const int g = lane >> 4, li = lane & 15;
     const int H = p.H, W = p.Wd;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    int t = blockIdx.x;
+    // 1-D grid, XCD-aware: every XCD gets a contiguous range of (spatial tile, output-channel block) pairs with the channel
+    // block fastest, so the channel blocks of one spatial tile run together on one XCD and share its L2 copy of the
+    // input halo (measured before: FETCH_SIZE 1.5 GB per launch, the input re-read once per 64 output channels)
+    const int ncb = (p.N + 63) / 64;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = t % ncb; t /= ncb;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y; const int b = t / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
-    const int n0 = blockIdx.y * 64;
+    const int n0 = cb * 64;
     const int ctot = p.C1 + p.C2;
 
     const half_t* __restrict__ S1 = reinterpret_cast<const half_t*>(p.A);
@@ -84,13 +89,54 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
 
-    // fragment addressing
+    // fragment addressing.  Halo pixel hp holds its four 16-byte pieces at byte hp*64 + ((piece ^ swz(hp)) << 4); a
+    // lane reads piece g of pixel a_hp[i] + (dy*HW_ + dx).  Filter row n of tap t sits at t*4096 + n*64 + swizzled piece.
     int a_hp[4];                                     // halo pixel of (fragment i, lane) for the centre tap
 #pragma unroll
     for (int i = 0; i < 4; ++i) a_hp[i] = (2 * wave + (i >> 1) + 1) * HW_ + ((i & 1) * 16 + li + 1);
-    int b_off[4];
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem;
+    unsigned b_ad[4];                                // LDS byte address of W fragment j, tap 0, buffer 0
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int n = j * 16 + li; b_off[j] = n * 64 + ((g ^ swz(n)) << 4); }
+    for (int j = 0; j < 4; ++j) { const int n = j * 16 + li; b_ad[j] = lds0 + HALO_BYTES + n * 64 + ((g ^ swz(n)) << 4); }
+
+    // Fragment reads are raw ds_read_b128 issued ONE TAP AHEAD of their MFMAs (register double buffer) and retired by
+    // counted lgkmcnt waits: the LDS latency hides behind the 16 MFMAs of the previous tap instead of being exposed
+    // after every fragment (the compiler's own schedule waited lgkmcnt(0) every 4 MFMAs).
+    half8_t Af[2][4], Bf[2][4];
+#define CV_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define CV_WAIT(n, S)                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                    \
+                 : "+v"(Af[S][0]), "+v"(Af[S][1]), "+v"(Af[S][2]), "+v"(Af[S][3]), "+v"(Bf[S][0]), "+v"(Bf[S][1]), \
+                   "+v"(Bf[S][2]), "+v"(Bf[S][3])                                                               \
+                 :: "memory")
+    // reads of tap TAP into register set S; bbase = byte offset of the stage buffer
+#define CV_READ_TAP(TAP, S, bbase)                                                                              \
+    do {                                                                                                        \
+        constexpr int doff = ((TAP) / 3 - 1) * HW_ + ((TAP) % 3 - 1);                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            const unsigned ad = b_ad[j] + (bbase);                                                              \
+            CV_DSR(Bf[S][j], ad, (TAP) * 4096);                                                                 \
+        }                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+            const int hp = a_hp[i] + doff;                                                                      \
+            const unsigned ad = lds0 + (bbase) + hp * 64 + ((g ^ swz(hp)) << 4);                                \
+            CV_DSR(Af[S][i], ad, 0);                                                                            \
+        }                                                                                                       \
+    } while (0)
+#define CV_MMA_TAP(S)                                                                                           \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[S][i], Bf[S][j], acc[i][j], 0, 0, 0);     \
+    } while (0)
+#define CV_STEP(TAP, bbase)                                                                                     \
+    do {                                                                                                        \
+        if ((TAP) < 8) { CV_READ_TAP(((TAP) + 1) % 9, ((TAP) + 1) & 1, bbase); CV_WAIT(8, (TAP) & 1); }         \
+        else { CV_WAIT(0, (TAP) & 1); }                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        CV_MMA_TAP((TAP) & 1);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
 
     // double-buffered: the DMA of chunk ch+1 is in flight while chunk ch is multiplied (one barrier per chunk)
     auto stage = [&](int ch, int buf) {
@@ -126,23 +172,13 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
+        const unsigned bbase = buf * CONV_LDS;
+        CV_READ_TAP(0, 0, bbase);                        // first tap of the chunk (its latency is exposed once per chunk)
         if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
-        const unsigned char* cH = sH + buf * CONV_LDS;
-        const unsigned char* cW = sW + buf * CONV_LDS;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            TR::Frag bfr[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = TR::load_frag(reinterpret_cast<const half_t*>(cW + tap * 4096 + b_off[j]));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int hp = a_hp[i] + dy * HW_ + dx;
-                const TR::Frag afr = TR::load_frag(reinterpret_cast<const half_t*>(cH + hp * 64 + ((g ^ swz(hp)) << 4)));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) TR::mma(afr, bfr[j], acc[i][j]);
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        CV_STEP(0, bbase); CV_STEP(1, bbase); CV_STEP(2, bbase);
+        CV_STEP(3, bbase); CV_STEP(4, bbase); CV_STEP(5, bbase);
+        CV_STEP(6, bbase); CV_STEP(7, bbase); CV_STEP(8, bbase);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -249,7 +285,7 @@ int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
                                 160 * 1024) != hipSuccess) return (int)hipGetLastError();
     }
     const int tiles = batch * ((p.H + TH - 1) / TH) * ((p.Wd + TW - 1) / TW);
-    const dim3 grid(tiles, (p.N + 63) / 64);
+    const dim3 grid(tiles * ((p.N + 63) / 64));
     if (occ == 2) hipLaunchKernelGGL(conv3x3_halo_kernel<2>, grid, dim3(NTH), 2 * CONV_LDS, stream, p);
     else hipLaunchKernelGGL(conv3x3_halo_kernel<4>, grid, dim3(NTH), 2 * CONV_LDS, stream, p);
     return (int)hipGetLastError();
