@@ -119,6 +119,16 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
         qk = reinterpret_cast<half_t*>(which == 0 ? p.q_out : p.k_out);
         col_term = (long)h * p.L * p.hd + d;
     }
+    // OUT_QKV: token m -> (image b, token t, grid row gy, grid col gx), advanced by 16 tokens per fragment row without
+    // integer divisions; the window index of a grid coordinate is a float reciprocal (exact: coordinate * win < 2^21)
+    int tb = 0, tt = 0, tgy = 0, tgx = 0;
+    const float inv_win = 1.0f / (float)(p.win > 0 ? p.win : 1);
+    const bool fwin = p.win > 0 && p.gw <= 4096 && p.gh <= 4096 && p.win <= 256;
+    if (OMODE == OUT_QKV) {
+        const int m_first = mrow0 + li;
+        tb = m_first / p.ntok; tt = m_first - tb * p.ntok;
+        if (p.win > 0) { tgy = tt / p.gw; tgx = tt - tgy * p.gw; }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = mrow0 + i * 16 + li;
@@ -162,13 +172,20 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
                 }
             }
         } else {   // OUT_QKV, q or k columns
-            const int b = m / p.ntok, t = m - b * p.ntok;
-            int s_ = b, pos = t;
+            int s_ = tb, pos = tt;
             if (p.win > 0) {
-                const int gy = t / p.gw, gx = t - gy * p.gw;
-                const int wy = gy / p.win, wx = gx / p.win;
-                s_ = (b * p.nwy + wy) * p.nwx + wx;
-                pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
+                const int wy = fwin ? (int)(((float)tgy + 0.5f) * inv_win) : tgy / p.win;
+                const int wx = fwin ? (int)(((float)tgx + 0.5f) * inv_win) : tgx / p.win;
+                s_ = (tb * p.nwy + wy) * p.nwx + wx;
+                pos = (tgy - wy * p.win) * p.win + (tgx - wx * p.win);
+            }
+            // next fragment row: 16 tokens further
+            tt += 16; tgx += 16;
+            if (tt >= p.ntok) {
+                tt -= p.ntok; ++tb;
+                if (p.win > 0) { tgy = tt / p.gw; tgx = tt - tgy * p.gw; }
+            } else if (p.win > 0) {
+                while (tgx >= p.gw) { tgx -= p.gw; ++tgy; }
             }
             half_t* o = qk + ((long)s_ * p.heads * p.L + pos) * p.hd + col_term;
 #pragma unroll
@@ -196,37 +213,43 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
     half_t* vt = reinterpret_cast<half_t*>(p.vt_out);
     const int b0 = mb / p.ntok, t0 = mb - b0 * p.ntok;
     const bool fast = p.win == 0 && t0 + 15 < p.ntok && (t0 & 7) == 0;
-    // token -> offset inside one (s, h, d) row of V^T, for the 8 token pairs (window mode)
-    long poff[8]; bool pair_ok[8];
+    // token -> offset inside one (s, h, d) row of V^T for the 16 tokens (8 pairs), walked incrementally (no divisions
+    // per token; window index by float reciprocal, exact for coordinate * win < 2^21)
+    long po0[8], po1[8]; bool pair_ok[8];
     if (!fast) {
+        const float inv_win = 1.0f / (float)(p.win > 0 ? p.win : 1);
+        const bool fwin = p.win > 0 && p.gw <= 4096 && p.gh <= 4096 && p.win <= 256;
+        int b = b0, t = t0, gy = 0, gx = 0;
+        if (p.win > 0) { gy = t / p.gw; gx = t - gy * p.gw; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             long o[2];
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
-                const int mm = mb + 2 * u + w;
-                const int b = mm / p.ntok, t = mm - b * p.ntok;
                 int s_ = b, pos = t;
                 if (p.win > 0) {
-                    const int gy = t / p.gw, gx = t - gy * p.gw;
-                    const int wy = gy / p.win, wx = gx / p.win;
+                    const int wy = fwin ? (int)(((float)gy + 0.5f) * inv_win) : gy / p.win;
+                    const int wx = fwin ? (int)(((float)gx + 0.5f) * inv_win) : gx / p.win;
                     s_ = (b * p.nwy + wy) * p.nwx + wx;
                     pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
                 }
                 o[w] = (long)s_ * p.heads * p.hd * p.Lp + pos;
+                ++t; ++gx;
+                if (t >= p.ntok) { t = 0; ++b; gy = 0; gx = 0; }
+                else if (p.win > 0 && gx >= p.gw) { gx = 0; ++gy; }
             }
-            poff[u] = o[0];
+            po0[u] = o[0]; po1[u] = o[1];
             pair_ok[u] = (o[1] == o[0] + 1) && ((o[0] & 1) == 0);
-            if (!pair_ok[u]) poff[u] = -1 - (long)(mb + 2 * u);   // resolved per element below (rare: odd geometry)
         }
     }
+    const int c0 = nrow0 + li + p.n_off - 2 * p.D;              // v column of fragment row 0; +16 per fragment row
+    int h = c0 / p.hd, d = c0 - h * p.hd;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int n = nrow0 + i * 16 + li;
         const float bv = bvt[i];
-        const int c = n + p.n_off - 2 * p.D;
-        const int h = c / p.hd, d = c - h * p.hd;
         const long rowoff = ((long)h * p.hd + d) * p.Lp;
+        d += 16;
+        while (d >= p.hd) { d -= p.hd; ++h; }
         if (fast) {
             half_t* dst = vt + (long)b0 * p.heads * p.hd * p.Lp + rowoff + t0;
 #pragma unroll
@@ -243,21 +266,10 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
                 if (pair_ok[u]) {
                     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
                     const half2_t w = {v0, v1};
-                    *reinterpret_cast<half2_t*>(vt + poff[u] + rowoff) = w;
+                    *reinterpret_cast<half2_t*>(vt + po0[u] + rowoff) = w;
                 } else {
-#pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        const int mm = (int)(-1 - poff[u]) + w;
-                        const int b = mm / p.ntok, t = mm - b * p.ntok;
-                        int s_ = b, pos = t;
-                        if (p.win > 0) {
-                            const int gy = t / p.gw, gx = t - gy * p.gw;
-                            const int wy = gy / p.win, wx = gx / p.win;
-                            s_ = (b * p.nwy + wy) * p.nwx + wx;
-                            pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
-                        }
-                        vt[(long)s_ * p.heads * p.hd * p.Lp + rowoff + pos] = w ? v1 : v0;
-                    }
+                    vt[po0[u] + rowoff] = v0;
+                    vt[po1[u] + rowoff] = v1;
                 }
             }
         }
@@ -272,6 +284,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int tiles_n = p.N / G8_BN, tiles_m = p.M / G8_BM, ntiles = tiles_m * tiles_n;
+    const int nk = p.K / G8_BK;                     // even, >= 2 (host)
 
     // ---- per-tile state.  (m0, n0, swap) of the tile being computed / stored; the DMA row offsets and bases below
     // always describe the tile whose DMA is issued NEXT (they are advanced to tile t+1 before tile t's epilogue).
@@ -284,10 +297,16 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     unsigned a_voff[4], w_voff[4];
     const unsigned char* Ab;
     const unsigned char* Wb;
+    // K direction of the tile whose DMA is issued next: a workgroup's consecutive tiles share their A panel (same tile
+    // row, next columns), so every other tile walks K BACKWARDS — the panel's most recently streamed K slices are
+    // still in L2 when the next tile starts from that end.
+    int kstart = 0, kstep = 1;
     auto tile_setup = [&](int tile, int& m0, int& n0, bool& swap) {
         int tm, tn;
         tile_coords(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
         m0 = tm * G8_BM; n0 = tn * G8_BN;
+        const bool rev = ((tile / (int)gridDim.x) & 1) && !(p.dbg & 128);
+        kstart = rev ? nk - 1 : 0; kstep = rev ? -1 : 1;
         // v columns of the fused qkv projection: exchange the operands (see epilogue8_vt); block-uniform
         swap = OMODE == OUT_QKV && TRANS == 1 && (n0 + p.n_off) >= 2 * p.D;
 #pragma unroll
@@ -317,13 +336,13 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), \
                  "s"(ldsaddr) : "memory")
     auto stage_a = [&](int buf, int kt) {
-        const unsigned char* base = uniform_ptr(Ab + (long)kt * (G8_BK * 2));
+        const unsigned char* base = uniform_ptr(Ab + (long)(kstart + kt * kstep) * (G8_BK * 2));
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G8_TILE + wave * 4096);
 #pragma unroll
         for (int i = 0; i < 4; ++i) G8_DMA(a_voff[i], base, dst + i * 1024);
     };
     auto stage_w = [&](int buf, int kt) {
-        const unsigned char* base = uniform_ptr(Wb + (long)kt * (G8_BK * 2));
+        const unsigned char* base = uniform_ptr(Wb + (long)(kstart + kt * kstep) * (G8_BK * 2));
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + G8_WOFF + buf * G8_TILE + wave * 4096);
 #pragma unroll
         for (int i = 0; i < 4; ++i) G8_DMA(w_voff[i], base, dst + i * 1024);
@@ -365,7 +384,6 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
                    "+v"(a[3][0]), "+v"(a[3][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1])       \
                  :: "memory")
 
-    const int nk = p.K / G8_BK;                     // even, >= 2 (host)
     constexpr bool no_dma = ABL & 1, no_rd = ABL & 2, no_epi = ABL & 4;   // experiment instantiations (CVA_GEMM_DBG), ABL = 0 in production
 
     // E <- tile 0, O <- tile 1 of the K loop (16 DMA loads per lane); wave 0 first fetches the tile's 256 bias values

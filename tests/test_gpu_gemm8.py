@@ -66,3 +66,33 @@ def test_attention_qkv_8phase(B, gh, gw, heads, D, win):
     torch.cuda.synchronize()
     ref = _attention_ref(xd.float().cpu(), Wd.float().cpu(), bqkv, tab_h, tab_w, B, gh, gw, 0, heads, D, win)
     assert _rel_err(out.float().cpu(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("B,gh,gw,has_cls,heads,D,win,rel", [
+    (2, 14, 14, 0, 6, 384, 0, False),     # 196 keys, hd 64, no bias   -> attnw_kernel<64, 0>
+    (2, 14, 14, 1, 6, 384, 0, False),     # 197 keys (cls token), ragged last key block
+    (1, 28, 28, 0, 12, 768, 14, True),    # SAM-B windows, hd 64, rel-pos -> attnw_kernel<64, 1>
+    (1, 14, 14, 0, 16, 1280, 0, False),   # hd 80, no bias              -> attnw_kernel<80, 0>
+    (1, 30, 30, 0, 16, 1280, 14, True),   # SAM-H windows with padded edge windows (30 -> 42)
+])
+def test_attention_short_sequences(B, gh, gw, has_cls, heads, D, win, rel):
+    """fp16 sequences of <= 208 keys run the single-pass window kernel (attention_win.hip)."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(7)
+    hd = D // heads
+    ntok = gh * gw + has_cls
+    x = torch.randn(B * ntok, D, generator=g)
+    Wqkv = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
+    bqkv = torch.randn(3 * D, generator=g) * 0.3
+    KH, KW = (win, win) if win else (gh, gw)
+    tab_h = torch.randn(2 * KH - 1, hd, generator=g) * 0.2 if rel else None
+    tab_w = torch.randn(2 * KW - 1, hd, generator=g) * 0.2 if rel else None
+    xd, Wd = _dev(x, F16), _dev(Wqkv, F16)
+    out = torch.zeros(B * ntok, D, device="cuda", dtype=torch.float16)
+    bd = bqkv.cuda()
+    thd, twd = (tab_h.cuda(), tab_w.cuda()) if rel else (None, None)
+    L.check(lib.cv_op_attention(F16, _p(xd), _p(Wd), _p(bd), _p(thd), _p(twd), _p(out), B, gh, gw, has_cls, heads,
+                                D, win, None))
+    torch.cuda.synchronize()
+    ref = _attention_ref(xd.float().cpu(), Wd.float().cpu(), bqkv, tab_h, tab_w, B, gh, gw, has_cls, heads, D, win)
+    assert _rel_err(out.float().cpu(), ref) < 1e-2
