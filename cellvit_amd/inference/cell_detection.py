@@ -14,7 +14,7 @@ wsi_datamodel.py:50-146).  Outputs under ``<patched_slide_path>/cell_detection[/
 Per tile everything up to the instance records runs on the GPU (forward, post-processing, token pooling); with
 ``torch.distributed`` initialised (one process per GPU) the tile list is sharded and margin-cell records are
 all-gathered for the slide-level de-duplication (row f1 of SURVEY §8: the reference uses shapely STRtree polygon
-intersections, unavailable here — this module applies the same rules with a raster overlap test; logged as such).
+intersections, unavailable here — this module applies the same rules with its own exact polygon-intersection area).
 """
 from __future__ import annotations
 
@@ -206,36 +206,72 @@ def _np_default(o):
 
 
 # ----------------------------------------------------------------------------------------------------
-# slide-level de-duplication (CellPostProcessor, cell_detection.py:600-767) — rules kept, geometry rasterised
+# slide-level de-duplication (CellPostProcessor, cell_detection.py:600-767) — same rules, exact polygon geometry
 # ----------------------------------------------------------------------------------------------------
-def _poly_mask(contour: np.ndarray, x0: int, y0: int, w: int, h: int) -> np.ndarray:
-    """Even-odd scanline fill of a closed polygon at pixel centres."""
+def _poly_area(contour: np.ndarray) -> float:
+    """Area of the closed polygon through the contour points (shoelace), as `shapely.Polygon(contour).area`."""
     pts = np.asarray(contour, dtype=np.float64)
-    mask = np.zeros((h, w), dtype=bool)
-    n = len(pts)
-    if n < 3:
-        return mask
-    xs, ys = pts[:, 0] - x0, pts[:, 1] - y0
-    for yy in range(h):
-        yc = yy + 0.5
-        xi = []
-        for i in range(n):
-            j = (i + 1) % n
-            if (ys[i] <= yc < ys[j]) or (ys[j] <= yc < ys[i]):
-                xi.append(xs[i] + (yc - ys[i]) * (xs[j] - xs[i]) / (ys[j] - ys[i]))
-        xi.sort()
-        for a, b in zip(xi[0::2], xi[1::2]):
-            mask[yy, max(int(math.ceil(a - 0.5)), 0):max(int(math.floor(b - 0.5)) + 1, 0)] = True
-    return mask
+    if len(pts) < 3:
+        return 0.0
+    x, y = pts[:, 0], pts[:, 1]
+    return 0.5 * abs(float(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))))
+
+
+def _edge_crossings_y(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """y coordinates of all proper intersection points between the edges of polygons a and b."""
+    a0, a1 = a, np.roll(a, -1, axis=0)
+    b0, b1 = b, np.roll(b, -1, axis=0)
+    da, db = (a1 - a0)[:, None, :], (b1 - b0)[None, :, :]
+    w = (b0[None, :, :] - a0[:, None, :])
+    den = da[..., 0] * db[..., 1] - da[..., 1] * db[..., 0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = (w[..., 0] * db[..., 1] - w[..., 1] * db[..., 0]) / den
+        u = (w[..., 0] * da[..., 1] - w[..., 1] * da[..., 0]) / den
+    ok = (den != 0) & (t > 0) & (t < 1) & (u > 0) & (u < 1)
+    ys = a0[:, None, 1] + t * da[..., 1]
+    return ys[ok]
+
+
+def _x_intervals(poly: np.ndarray, yc: float) -> np.ndarray:
+    """Sorted x coordinates where the horizontal line y = yc crosses the polygon's edges (even-odd interior:
+    [x0, x1], [x2, x3], ...)."""
+    p0, p1 = poly, np.roll(poly, -1, axis=0)
+    y0, y1 = p0[:, 1], p1[:, 1]
+    hit = ((y0 <= yc) & (yc < y1)) | ((y1 <= yc) & (yc < y0))
+    xs = p0[hit, 0] + (yc - y0[hit]) * (p1[hit, 0] - p0[hit, 0]) / (y1[hit] - y0[hit])
+    return np.sort(xs)
+
+
+def _intersection_area(a: np.ndarray, b: np.ndarray) -> float:
+    """EXACT area of the intersection of two polygons (even-odd interiors) by slab decomposition: between two
+    consecutive event ordinates (vertices of either polygon, crossings of an a-edge with a b-edge) every interval end
+    point is linear in y, so the common length L(y) is linear and the midpoint rule integrates it exactly."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    if len(a) < 3 or len(b) < 3:
+        return 0.0
+    lo, hi = max(a[:, 1].min(), b[:, 1].min()), min(a[:, 1].max(), b[:, 1].max())
+    if hi <= lo or max(a[:, 0].min(), b[:, 0].min()) >= min(a[:, 0].max(), b[:, 0].max()):
+        return 0.0
+    ev = np.concatenate([a[:, 1], b[:, 1], _edge_crossings_y(a, b), [lo, hi]])
+    ev = np.unique(ev[(ev >= lo) & (ev <= hi)])
+    area = 0.0
+    for y0, y1 in zip(ev[:-1], ev[1:]):
+        ym = 0.5 * (y0 + y1)
+        xa, xb = _x_intervals(a, ym), _x_intervals(b, ym)
+        length = 0.0
+        for i in range(0, len(xa) - 1, 2):
+            for j in range(0, len(xb) - 1, 2):
+                length += max(0.0, min(xa[i + 1], xb[j + 1]) - max(xa[i], xb[j]))
+        area += length * (y1 - y0)
+    return area
 
 
 def _overlap_fractions(ca: dict, cb: dict) -> Tuple[float, float, float, float]:
+    """(intersection / area_a, intersection / area_b, area_a, area_b) of two cells' contour polygons — the quantities
+    the reference takes from shapely (`cell_detection.py:722-747`), computed exactly (no shapely here)."""
     a, b = np.asarray(ca["contour"]), np.asarray(cb["contour"])
-    x0, y0 = int(min(a[:, 0].min(), b[:, 0].min())), int(min(a[:, 1].min(), b[:, 1].min()))
-    x1, y1 = int(max(a[:, 0].max(), b[:, 0].max())) + 2, int(max(a[:, 1].max(), b[:, 1].max())) + 2
-    ma, mb = _poly_mask(a, x0, y0, x1 - x0, y1 - y0), _poly_mask(b, x0, y0, x1 - x0, y1 - y0)
-    inter = float((ma & mb).sum())
-    aa, ab = float(ma.sum()), float(mb.sum())
+    aa, ab = _poly_area(a), _poly_area(b)
+    inter = _intersection_area(a, b) if aa > 0 and ab > 0 else 0.0
     return (inter / aa if aa else 0.0), (inter / ab if ab else 0.0), aa, ab
 
 

@@ -50,9 +50,22 @@ def test_stitch_rules():
     assert keep == [0, 2, 4]
 
 
-def test_poly_mask_area():
-    m = CD._poly_mask(np.array([[2, 2], [2, 8], [10, 8], [10, 2]]), 0, 0, 12, 12)
-    assert m.sum() == 8 * 6
+def test_polygon_geometry_exact():
+    sq = np.array([[2, 2], [2, 8], [10, 8], [10, 2]])                       # 8 x 6 rectangle
+    assert CD._poly_area(sq) == 48.0
+    assert CD._intersection_area(sq, sq + np.array([4, 0])) == 4 * 6       # shifted by 4 in x
+    assert CD._intersection_area(sq, sq + np.array([20, 0])) == 0.0
+    tri = np.array([[0, 0], [8, 0], [0, 8]])                               # right triangle, area 32
+    assert CD._poly_area(tri) == 32.0
+    box = np.array([[0, 0], [4, 0], [4, 4], [0, 4]])
+    assert abs(CD._intersection_area(tri, box) - 16.0) < 1e-12             # the box lies inside the triangle (x + y <= 8)
+    box2 = box + np.array([3, 3])                                          # [3,7]^2 cut by x + y = 8: corner triangle of legs 2
+    assert abs(CD._intersection_area(tri, box2) - 2.0) < 1e-12
+    ell = np.array([[0, 0], [6, 0], [6, 2], [2, 2], [2, 6], [0, 6]])       # concave L, area 20
+    assert CD._poly_area(ell) == 20.0
+    assert abs(CD._intersection_area(ell, np.array([[1, 1], [5, 1], [5, 5], [1, 5]])) - (4 + 3 + 0)) < 1e-12
+    fa, fb, aa, ab = CD._overlap_fractions({"contour": sq}, {"contour": sq + np.array([4, 0])})
+    assert (fa, fb, aa, ab) == (0.5, 0.5, 48.0, 48.0)
 
 
 @pytest.mark.gpu
