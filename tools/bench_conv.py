@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 from cellvit_amd import _lib  # noqa: E402
 
-SHAPES = [  # (H, C1, C2, Cout)
+SHAPES_ALL = [  # (H, C1, C2, Cout)
     (128, 512, 512, 512), (128, 512, 0, 512), (256, 256, 256, 256), (256, 256, 0, 256),
     (512, 128, 128, 128), (512, 128, 0, 128), (1024, 64, 64, 64), (1024, 64, 0, 64), (1024, 32, 0, 64),
 ]
@@ -18,6 +18,8 @@ SHAPES = [  # (H, C1, C2, Cout)
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    sel = os.environ.get("CONV_SHAPES")          # e.g. CONV_SHAPES=7,5,1
+    SHAPES = [SHAPES_ALL[int(i)] for i in sel.split(",")] if sel else SHAPES_ALL[:8]
     B = 8
     lib = _lib.load()
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
