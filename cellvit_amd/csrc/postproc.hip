@@ -447,6 +447,7 @@ struct FloodParams {
     int* queue_head;                                          // [B] dequeue cursors
     u64* ovf_hi; u64* ovf_lo; int* ovf_lab; u64* ovf_cursor;  // overflow arena [B][N]
     int H, W, B;
+    int dbg;
 };
 
 // Pool entries are 128-bit keys: hi = order-preserving image of the f64 distance value, lo = age << 42 | pixel
@@ -488,6 +489,9 @@ __device__ __forceinline__ Key2 wave_min_key(Key2 k) {
     return r;
 }
 
+// One workgroup = ONE wavefront, so LDS operations execute in program order and the fences below only need wavefront
+// scope (compiler ordering).  A workgroup-scope release would also drain the fire-and-forget global stores of the labels
+// (s_waitcnt vmcnt(0)) on every pop — measured: that wait, not the pool scan, was the per-pop cost.
 __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
     __shared__ u64 s_hi[POOL_LDS];
     __shared__ u64 s_lo[POOL_LDS];
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                 }
                 append(have, v, 0u, idx, lab);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
             // ---- ordered flood ----
             while (n > 0) {
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                     const int yy = py + dy, xx = px + dx;
                     if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
                         q = yy * W + xx;
-                        qv = dist[q];                                     // issued together with the claim
+                        qv = (p.dbg & 1) ? (double)(q & 1023) : dist[q];   // issued together with the claim
                         if (use_bits) {
                             if (yy >= by0 && yy <= by1 && xx >= bx0 && xx <= bx1) {
                                 const int loc = (yy - by0) * bw + (xx - bx0);
@@ -612,10 +616,10 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                 }
                 const u64 m = __ballot(have);
                 const unsigned myage = age + 1u + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the hole fill above precedes the appends
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the hole fill above precedes the appends
                 append(have, qv, myage, q, plab);
                 age += (unsigned)__popcll(m);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
         }
     }
@@ -929,6 +933,7 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     fp.comp_list = w->comp_list; fp.comp_count = comp_count; fp.list_cap = w->list_cap; fp.queue_head = queue_head;
     fp.ovf_hi = reinterpret_cast<unsigned long long*>(w->ovf_v); fp.ovf_lo = w->ovf_lo; fp.ovf_lab = w->ovf_lab; fp.ovf_cursor = w->ovf_cursor;
     fp.H = H; fp.W = W; fp.B = B;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CVA_PP_DBG"); dbg = e ? atoi(e) : 0; } fp.dbg = dbg; }
     hipLaunchKernelGGL(k_flood, dim3(1024, B), dim3(64), 0, st, fp);
     // ---- P7/P8: per-instance records + contours ----
     CVA_MS(w->st.cnt, 0, S * 4); CVA_MS(w->st.sx, 0, S * 8); CVA_MS(w->st.sy, 0, S * 8);
