@@ -56,8 +56,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out_) + (long)row * C + idx * 4) = y;
             } else {
                 T* o = reinterpret_cast<T*>(out_) + (long)row * C + idx * 4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = Traits<T>::from_float(y[j]);
+                if constexpr (sizeof(T) == 2) {      // one 8-byte store per lane (a wave writes 512 contiguous bytes)
+                    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                    const half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+                    *reinterpret_cast<half4_t*>(o) = h;
+                } else {
+                    *reinterpret_cast<f32x4*>(o) = y;
+                }
             }
         }
     }
