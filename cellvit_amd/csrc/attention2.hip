@@ -290,47 +290,62 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
                 }
             }
         }
-        // ---- online softmax per query (lane-local + the 4 lanes li, li+16, li+32, li+48) ----
-        // everything in the log2 domain: v = s * (scale*log2e) + bias*log2e ; p = 2^(v - m)
+        // ---- online softmax per query, LAZY reference maximum (log2 domain) ----
+        //   t = s * (scale*log2e) [+ kw bias];  p = 2^(t + bh - m_ref)
+        // m_ref is only raised when some score of the tile exceeds it by more than LAZY_TAU (checked wave-wide with one
+        // ballot); otherwise the tile needs NO cross-lane reduction and NO rescale of the output accumulators — p may then
+        // be as large as 2^LAZY_TAU, harmless in fp16/fp32.  The row sum is kept as a per-lane partial (the four lanes
+        // of a query are combined once, after the key loop).  Mathematically identical to the eager form.
+        constexpr float LAZY_TAU = 8.0f;
         const bool ragged = (kt == ntiles - 1) && (p.nk & (KT - 1)) != 0;     // only the last tile can hold invalid keys
         Frag pf[2][2];
+        float tmax[2], bh[2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            float bh = 0.f;
-            if (BIAS == 2) bh = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + kt]) * c1;   // kh == kt
+            bh[qb] = 0.f;
+            if (BIAS == 2) bh[qb] = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + kt]) * c1;   // kh == kt
             float mx = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = s[qb][kb][r] * c1;
-                    if (BIAS == 2) v += bw[qb][kb][r] + bh;
+                    float v = BIAS == 2 ? fmaf(s[qb][kb][r], c1, bw[qb][kb][r]) : s[qb][kb][r] * c1;
                     if (ragged) { const int key = kt * KT + kb * 16 + g * 4 + r; v = key < p.nk ? v : -INFINITY; }
                     s[qb][kb][r] = v;
                     mx = fmaxf(mx, v);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mn = fmaxf(m_run[qb], mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - mn);
-            m_run[qb] = mn;
+            tmax[qb] = mx + bh[qb];
+        }
+        if (__any((tmax[0] > m_run[0] + LAZY_TAU) || (tmax[1] > m_run[1] + LAZY_TAU))) {      // wave-uniform, rare after the first tiles
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float mx = tmax[qb];
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mn = fmaxf(m_run[qb], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - mn);   // first tile: 2^(-inf) = 0 on zero accumulators
+                m_run[qb] = mn;
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int n = 0; n < ND; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qb][n][r] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float shift = bh[qb] - m_run[qb];
             float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[qb][kb][r] - mn);
+                    const float pv = __builtin_amdgcn_exp2f(s[qb][kb][r] + shift);
                     rs += pv;
                     // contraction slot (m, g*8 + j): j < 4 -> key block 2m, reg j ; j >= 4 -> key block 2m+1, reg j-4
                     set_frag<T>(pf[qb][kb >> 1], (kb & 1) * 4 + r, pv);
                 }
-            rs += __shfl_xor(rs, 16);
-            rs += __shfl_xor(rs, 32);
-            l_run[qb] = l_run[qb] * alpha + rs;
-#pragma unroll
-            for (int n = 0; n < ND; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[qb][n][r] *= alpha;
+            l_run[qb] += rs;                                       // per-lane partial row sum
         }
         // ---- O^T += V^T P^T : A = V^T rows d = n*16 + li, keys (2m)*16 + g*4 + {0..3} and (2m+1)*16 + g*4 + {0..3} ----
 #pragma unroll
@@ -351,6 +366,9 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     T* __restrict__ out = reinterpret_cast<T*>(p.out);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
+        float lsum = l_run[qb];                                // combine the four lanes' partial row sums (all lanes active)
+        lsum += __shfl_xor(lsum, 16);
+        lsum += __shfl_xor(lsum, 32);
         const int qg = q0 + qb * 16 + li;
         if (qg >= p.L) continue;
         long row;
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
         } else {
             row = (long)s_idx * p.ntok + qg;
         }
-        const float inv = 1.0f / l_run[qb];
+        const float inv = 1.0f / lsum;
 #pragma unroll
         for (int n = 0; n < ND; ++n) {
             typename Pack4<T>::type v;
