@@ -20,6 +20,8 @@
 //          scalar per query and tile), the kw term is tile-invariant and lives in registers.
 #include "attention.h"
 
+#include <type_traits>
+
 namespace cva {
 
 namespace {
@@ -54,9 +56,11 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     using Frag = typename TR::Frag;
     constexpr int PE = TR::PIECE;
     constexpr int HDP = (HD + 31) / 32 * 32, NKS = HDP / 32, ND = HD / 16;
-    // V^T rows are read as 8-byte halves of a fragment (two ds_read_b64 per lane): a 144-byte pitch spreads the 16
-    // rows of a lane group over distinct bank pairs (160 B would alias rows r and r+8).
-    constexpr int PK = lds_pitch<T>(HDP), PV = sizeof(T) == 2 ? KT + 8 : lds_pitch<T>(KT);
+    // V^T rows are read as 8-byte halves of a fragment, which the compiler merges into ds_read2_b64 (32-bank mapping):
+    // a 136-byte pitch (34 dwords) puts the 16 rows of a lane group on 16 distinct bank pairs under both the 32- and the
+    // 64-bank mapping (144 B collided pairwise: SQ_LDS_BANK_CONFLICT was 1.7x the kernel's active LDS cycles).  Rows are
+    // then only 8-byte aligned, so the staging writes of V^T are two 8-byte stores per piece.
+    constexpr int PK = lds_pitch<T>(HDP), PV = sizeof(T) == 2 ? KT + 4 : lds_pitch<T>(KT);
     constexpr int EW = NBK * 32;                       // one-hot width (BIAS 1)
     constexpr int PE1 = lds_pitch<T>(EW);              // pitch of E and relcat rows (BIAS 1)
     constexpr int RC2 = 128 + 8;                       // relcat row pitch (BIAS 2): KH + KW <= 128
@@ -105,13 +109,16 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     constexpr int KPPR = HD / PE, VPPR = KT / PE;
     constexpr int KN = (KT * KPPR + NT - 1) / NT, VN = (HD * VPPR + NT - 1) / NT;
     Piece kreg[KN], vreg[VN];
-    auto fetch = [&](int kt) {
+    // LAST (compile time): only the last key tile can hold keys >= nk; every other tile skips the bounds tests and the
+    // per-element tail zeroing (the optimiser turned those into ~140 selects per tile, executed on every tile)
+    auto fetch = [&](int kt, auto lastc) {
+        constexpr bool LAST = decltype(lastc)::value;
 #pragma unroll
         for (int u = 0; u < KN; ++u) {
             const int i = tid + u * NT;
             const int r = i / KPPR, c = i - r * KPPR;
             const int key = kt * KT + r;
-            kreg[u] = (i < KT * KPPR && key < p.nk) ? load_piece(Kg + (long)key * HD + c * PE) : zero_piece();
+            kreg[u] = (i < KT * KPPR && (!LAST || key < p.nk)) ? load_piece(Kg + (long)key * HD + c * PE) : zero_piece();
         }
 #pragma unroll
         for (int u = 0; u < VN; ++u) {
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             Piece v = zero_piece();
             if (i < HD * VPPR) {
                 v = load_piece(Vg + (long)d * p.Lp + key0);
-                if (key0 + PE > p.nk) {                 // never let stale bytes past the last key meet P = 0
+                if (LAST && key0 + PE > p.nk) {         // never let stale bytes past the last key meet P = 0
                     T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
                     for (int j = 0; j < PE; ++j) if (key0 + j >= p.nk) e[j] = TR::from_float(0.f);
@@ -130,7 +137,10 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             vreg[u] = v;
         }
     };
-    fetch(0);                                          // in flight during the rel-pos prologue
+    const int ntiles = (p.nk + KT - 1) / KT;
+    const std::integral_constant<bool, true> LAST_T{};
+    const std::integral_constant<bool, false> FULL_T{};
+    if (ntiles == 1) fetch(0, LAST_T); else fetch(0, FULL_T);
 
     // ---- decomposed rel-pos: relcat[q][kh] = q·tab_h[qy-kh+KH-1] / scale ; relcat[q][KH+kw] likewise ----
     const float inv_scale = 1.0f / p.scale;
@@ -233,8 +243,8 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
 
     const bool wave_active = q0 < p.L;                 // waves whose 32 queries are all padding only help staging
 
-    const int ntiles = (p.nk + KT - 1) / KT;
-    for (int kt = 0; kt < ntiles; ++kt) {
+    auto step = [&](const int kt, auto lastc) {
+        constexpr bool LAST = decltype(lastc)::value;
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < KN; ++u) {
@@ -244,7 +254,16 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
 #pragma unroll
         for (int u = 0; u < VN; ++u) {
             const int i = tid + u * NT;
-            if (i < HD * VPPR) { const int d = i / VPPR, c = i - d * VPPR; store_piece(Vts + d * PV + c * PE, vreg[u]); }
+            if (i < HD * VPPR) {
+                const int d = i / VPPR, c = i - d * VPPR;
+                if constexpr (sizeof(T) == 2) {
+                    unsigned long long* dst = reinterpret_cast<unsigned long long*>(Vts + d * PV + c * PE);
+                    dst[0] = ((unsigned long long)vreg[u].w[1] << 32) | vreg[u].w[0];
+                    dst[1] = ((unsigned long long)vreg[u].w[3] << 32) | vreg[u].w[2];
+                } else {
+                    store_piece(Vts + d * PV + c * PE, vreg[u]);
+                }
+            }
         }
         if (BIAS == 1) {   // one-hot rows E[key][kh] = E[key][KH + kw] = 1
             constexpr int PPR = EW / PE;
@@ -265,9 +284,9 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             }
         }
         __syncthreads();
-        if (kt + 1 < ntiles) fetch(kt + 1);
-        if (!wave_active) continue;
-        const int nkb = min(4, (p.nk - kt * KT + 15) / 16);      // key blocks of this tile that hold real keys
+        if (!LAST) { if (kt + 2 == ntiles) fetch(kt + 1, LAST_T); else fetch(kt + 1, FULL_T); }
+        if (!wave_active) return;
+        const int nkb = LAST ? min(4, (p.nk - kt * KT + 15) / 16) : 4;      // key blocks of this tile that hold real keys
 
         // ---- S^T blocks: s[qb][kb][r] = score(query li of qb, key kb*16 + g*4 + r) / scale ----
         f32x4 s[2][4];
@@ -297,7 +316,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
         // be as large as 2^LAZY_TAU, harmless in fp16/fp32.  The row sum is kept as a per-lane partial (the four lanes
         // of a query are combined once, after the key loop).  Mathematically identical to the eager form.
         constexpr float LAZY_TAU = 8.0f;
-        const bool ragged = (kt == ntiles - 1) && (p.nk & (KT - 1)) != 0;     // only the last tile can hold invalid keys
+        const bool ragged = LAST && (p.nk & (KT - 1)) != 0;                   // only the last tile can hold invalid keys
         Frag pf[2][2];
         float tmax[2], bh[2];
 #pragma unroll
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = BIAS == 2 ? fmaf(s[qb][kb][r], c1, bw[qb][kb][r]) : s[qb][kb][r] * c1;
-                    if (ragged) { const int key = kt * KT + kb * 16 + g * 4 + r; v = key < p.nk ? v : -INFINITY; }
+                    if (LAST && ragged) { const int key = kt * KT + kb * 16 + g * 4 + r; v = key < p.nk ? v : -INFINITY; }
                     s[qb][kb][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -359,7 +378,9 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
                 TR::mma(vf, pf[1][m], o[1][n]);
             }
         }
-    }
+    };
+    for (int kt = 0; kt + 1 < ntiles; ++kt) step(kt, FULL_T);
+    step(ntiles - 1, LAST_T);
 
     // ---- normalise; lane holds O[query li of qb][d = n*16 + g*4 + r] ----
     const int s_idx = sh / p.heads, h = sh - s_idx * p.heads;
