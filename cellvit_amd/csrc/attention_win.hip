@@ -40,7 +40,9 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
     constexpr int PE = 8;
     constexpr int HDP = (HD + 31) / 32 * 32, NKS = HDP / 32, ND = HD / 16;
     constexpr int PK = lds_pitch<half_t>(HDP);          // K tile / table row pitch
-    constexpr int PVF = WKEYS + 8;                      // V^T row pitch: 432 B -> the 16 rows of a lane group hit 16 distinct slots
+    constexpr int PVF = WKEYS + 4;                      // V^T row pitch 424 B = 106 dwords: the 16 rows of a lane group fall on 16 distinct
+                                                        // bank pairs under the 32-bank map of ds_read2_b64 (the compiler merges the two 8-byte
+                                                        // halves of a fragment read) AND the 64-bank map; rows are 8-byte aligned only
     constexpr int PE1 = 32 + 8;                         // E / relcat row pitch: 80 B (odd multiple of 16 B: conflict-free b128 reads)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smemw[];
@@ -134,7 +136,9 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
 #pragma unroll
                 for (int j = 0; j < PE; ++j) if (key0 + j >= p.nk) e[j] = (half_t)0.f;
             }
-            store_piece(Vts + d * PVF + c * PE, v);
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(Vts + d * PVF + c * PE);   // two 8-byte stores
+            dst[0] = ((unsigned long long)v.w[1] << 32) | v.w[0];
+            dst[1] = ((unsigned long long)v.w[3] << 32) | v.w[2];
         }
     }
     if (HDP > HD) {
@@ -341,7 +345,7 @@ __global__ void attnw_prep_kernel(const float* __restrict__ tab_h, const float* 
 template <int HD, int BIAS>
 int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
     constexpr int HDP = (HD + 31) / 32 * 32;
-    size_t lds = (size_t)(WKT * lds_pitch<half_t>(HDP) + HD * (WKEYS + 8)) * sizeof(half_t);
+    size_t lds = (size_t)(WKT * lds_pitch<half_t>(HDP) + HD * (WKEYS + 4) + 8) * sizeof(half_t);   // (+8: keeps Es 16-byte aligned)
     if (BIAS) lds += (size_t)(WKEYS + WQT) * 40 * sizeof(half_t);
     static bool attr_set = false;
     if (!attr_set) {
