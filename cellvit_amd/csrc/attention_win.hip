@@ -8,13 +8,15 @@
 //   S^T = K . Q^T  -> lane (g, li) holds keys kb*16 + g*4 + r of ONE query (li): row statistics are lane-local
 //                     plus two shuffles;
 //   O^T = V^T . P^T with P^T taken straight from the S^T registers (relabelled contraction index).
-// One workgroup = 4 waves x 32 queries of one (window, head).  K passes through LDS in 64-key tiles (all fetched up front),
+// One workgroup = 4 waves of one (window, head), which walk its queries in (up to) two passes of 4 x 32.  K passes through LDS in 64-key tiles (all fetched up front),
 // V^T (all keys) and the one-hot rel-pos matrix E[key][kh | KH + kw] (all keys) are staged once per workgroup.
 // The decomposed rel-pos bias (image_encoder.py:354-392) is one extra contraction step of the S^T MFMA against E,
 // with the per-query terms G = Q . tab^T computed by MFMA at block start (tables staged through LDS).
 #include "attention.h"
 
 #include <stdlib.h>
+
+#include <type_traits>
 
 namespace cva {
 
@@ -54,26 +56,28 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
     if (p.dbg & 8) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    // XCD-aware remap (see attention2.hip): both query halves of a (window, head) run on the same XCD
-    const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int q0 = (lin % gridDim.x) * WQT + wave * WQW;
-    const int sh = lin / gridDim.x;
+        // one workgroup per (sequence, head): its (up to) two passes of 128 queries share the staged V^T / E / K tiles
+    const int sh = xcd_remap(blockIdx.x, gridDim.x);
+    const int npass = p.L > WQT ? 2 : 1;                // block-uniform
 
     const half_t* __restrict__ Qg = reinterpret_cast<const half_t*>(p.Q) + (long)sh * p.L * HD;
     const half_t* __restrict__ Kg = reinterpret_cast<const half_t*>(p.K) + (long)sh * p.L * HD;
     const half_t* __restrict__ Vg = reinterpret_cast<const half_t*>(p.Vt) + (long)sh * HD * p.Lp;
 
-    // ---- Q fragments (B operand of S^T)
+    // ---- Q fragments (B operand of S^T): pass ps covers queries ps*128 + wave*32 + qb*16 + li
     half8_t qf[2][NKS];
+    auto load_q = [&](int ps) {
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int row = q0 + qb * 16 + li;
+        for (int qb = 0; qb < 2; ++qb) {
+            const int row = ps * WQT + wave * WQW + qb * 16 + li;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const int d0 = ks * 32 + g * 8;
-            qf[qb][ks] = (row < p.L && d0 < HD) ? *reinterpret_cast<const half8_t*>(Qg + (long)row * HD + d0) : (half8_t)(0);
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int d0 = ks * 32 + g * 8;
+                qf[qb][ks] = (row < p.L && d0 < HD) ? *reinterpret_cast<const half8_t*>(Qg + (long)row * HD + d0) : (half8_t)(0);
+            }
         }
-    }
+    };
+    load_q(0);
 
     // ---- K: all (<= 4) tiles of 64 keys are fetched into registers up front (48 VGPRs for hd 80): the key loop below then
     // contains no global-memory round trip at all
@@ -117,12 +121,15 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
             const int i = tid + u * WNT;
             ereg[u] = i < WKEYS * 4 ? load_piece(prepE + i * PE) : zero_piece();
         }
+    }
+    auto load_tf = [&]() {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)                  // tj = tbl*2 + jb: table rows tbl*32 + jb*16 + li
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
                 tf[tj][ks] = *reinterpret_cast<const half8_t*>(prepT + ((tj >> 1) * 32 + (tj & 1) * 16 + li) * HDP + ks * 32 + g * 8);
-    }
+    };
+    if (BIAS) load_tf();
     // ---- LDS writes: V^T (all keys), E, K tile 0 (+ zero pad columns of the K rows)
 #pragma unroll
     for (int u = 0; u < VN; ++u) {
@@ -158,167 +165,177 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
             const int i = tid + u * WNT;
             if (i < WKEYS * 4) store_piece(Es + (i >> 2) * PE1 + (i & 3) * PE, ereg[u]);
         }
-        // ---- relcat[q][kh] = q . tab_h[qy - kh + KH - 1] / scale ; relcat[q][KH + kw] likewise (image_encoder.py:347-351)
-        half_t* myrc = Rc + (wave * WQW) * PE1;
-        for (int i = lane; i < WQW * PE1 / PE; i += 64) store_piece(myrc + i * PE, zero_piece());
-        const float inv_scale = 1.0f / p.scale;
-#pragma unroll
-        for (int tbl = 0; tbl < 2; ++tbl) {
-            const int Ksz = tbl == 0 ? p.KH : p.KW;
-            const int off = tbl == 0 ? 0 : p.KH;
-            const int nj = 2 * Ksz - 1;
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) {
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    f32x4 acc = (f32x4)(0.f);
-#pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf[tbl * 2 + jb][ks], qf[qb][ks], acc, 0, 0, 0);
-                    const int q = q0 + qb * 16 + li;
-                    if (q < p.L) {
-                        const int qy = q / p.KW, qx = q - qy * p.KW;
-                        const int c = tbl == 0 ? qy : qx;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int jj = jb * 16 + g * 4 + r;
-                            const int kk = c - jj + Ksz - 1;
-                            if (jj < nj && kk >= 0 && kk < Ksz) myrc[(qb * 16 + li) * PE1 + off + kk] = (half_t)(acc[r] * inv_scale);
-                        }
-                    }
-                }
-            }
-        }
     }
-    __syncthreads();                                    // V^T / E / K tile 0 / relcat visible
+    __syncthreads();                                    // V^T / E / K tile 0 visible
 
-    half8_t bf[2];
-    if (BIAS) {
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) bf[qb] = *reinterpret_cast<const half8_t*>(Rc + (wave * WQW + qb * 16 + li) * PE1 + g * 8);
-    }
-
-    const bool wave_active = q0 < p.L && !(p.dbg & 2);
     const int ntiles = (p.nk + WKT - 1) / WKT;          // <= 4
     const int nkb_all = (p.nk + 15) / 16;               // <= 13
+    const float c1 = p.scale * W_LOG2E;
+    const int s_idx = sh / p.heads, h = sh - s_idx * p.heads;
+    half_t* __restrict__ out = reinterpret_cast<half_t*>(p.out);
 
-    // ---- S^T for all keys: s[qb][kg][r] = score(query li of qb, key kg*16 + g*4 + r) / scale
-    f32x4 s[2][WNKB];
+    auto run_pass = [&](auto passc) {
+        constexpr int PS = decltype(passc)::value;
+        const int q0 = PS * WQT + wave * WQW;
+        const bool wave_active = q0 < p.L && !(p.dbg & 2);
+        if (PS > 0 && wave_active) { load_q(PS); if (BIAS) load_tf(); }   // (the first pass' operands came with the prologue loads)
+
+        // ---- relcat[q][kh] = q . tab_h[qy - kh + KH - 1] / scale ; relcat[q][KH + kw] likewise (image_encoder.py:347-351);
+        // each wave fills and reads back only ITS rows of Rc (LDS is in order per wave: no barrier)
+        half8_t bf[2];
+        if (BIAS && wave_active) {
+            half_t* myrc = Rc + (wave * WQW) * PE1;
+            for (int i = lane; i < WQW * PE1 / PE; i += 64) store_piece(myrc + i * PE, zero_piece());
+            const float inv_scale = 1.0f / p.scale;
 #pragma unroll
-    for (int kg = 0; kg < WNKB; ++kg) { s[0][kg] = (f32x4)(0.f); s[1][kg] = (f32x4)(0.f); }
+            for (int tbl = 0; tbl < 2; ++tbl) {
+                const int Ksz = tbl == 0 ? p.KH : p.KW;
+                const int off = tbl == 0 ? 0 : p.KH;
+                const int nj = 2 * Ksz - 1;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (t < ntiles) {                               // block-uniform
-            if (t > 0) {
-                __syncthreads();                        // every wave is done reading tile t-1
+                for (int jb = 0; jb < 2; ++jb) {
 #pragma unroll
-                for (int u = 0; u < KN; ++u) {
-                    const int i = tid + u * WNT;
-                    if (i < WKT * KPPR) { const int r = i / KPPR, c = i - r * KPPR; store_piece(Ks + r * PK + c * PE, kreg[t][u]); }
-                }
-                __syncthreads();
-            }
-            if (wave_active) {
+                    for (int qb = 0; qb < 2; ++qb) {
+                        f32x4 acc = (f32x4)(0.f);
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const int kg = t * 4 + kb;
-                    if (kg < WNKB && kg < nkb_all) {
+                        for (int ks = 0; ks < NKS; ++ks)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf[tbl * 2 + jb][ks], qf[qb][ks], acc, 0, 0, 0);
+                        const int q = q0 + qb * 16 + li;
+                        if (q < p.L) {
+                            const int qy = q / p.KW, qx = q - qy * p.KW;
+                            const int c = tbl == 0 ? qy : qx;
 #pragma unroll
-                        for (int ks = 0; ks < NKS; ++ks) {
-                            const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kb * 16 + li) * PK + ks * 32 + g * 8);
-                            s[0][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], s[0][kg < WNKB ? kg : 0], 0, 0, 0);
-                            s[1][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], s[1][kg < WNKB ? kg : 0], 0, 0, 0);
+                            for (int r = 0; r < 4; ++r) {
+                                const int jj = jb * 16 + g * 4 + r;
+                                const int kk = c - jj + Ksz - 1;
+                                if (jj < nj && kk >= 0 && kk < Ksz) myrc[(qb * 16 + li) * PE1 + off + kk] = (half_t)(acc[r] * inv_scale);
+                            }
                         }
-                        if (BIAS) {
-                            const half8_t ef = *reinterpret_cast<const half8_t*>(Es + (kg * 16 + li) * PE1 + g * 8);
-                            s[0][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ef, bf[0], s[0][kg < WNKB ? kg : 0], 0, 0, 0);
-                            s[1][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ef, bf[1], s[1][kg < WNKB ? kg : 0], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) bf[qb] = *reinterpret_cast<const half8_t*>(myrc + (qb * 16 + li) * PE1 + g * 8);
+        }
+
+        // ---- S^T for all keys: s[qb][kg][r] = score(query li of qb, key kg*16 + g*4 + r) / scale
+        f32x4 s[2][WNKB];
+#pragma unroll
+        for (int kg = 0; kg < WNKB; ++kg) { s[0][kg] = (f32x4)(0.f); s[1][kg] = (f32x4)(0.f); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < ntiles) {                               // block-uniform
+                if (t > 0 || PS > 0) {                      // (tile 0 of pass 0 was staged by the prologue)
+                    __syncthreads();                        // every wave is done reading the previous tile
+#pragma unroll
+                    for (int u = 0; u < KN; ++u) {
+                        const int i = tid + u * WNT;
+                        if (i < WKT * KPPR) { const int r = i / KPPR, c = i - r * KPPR; store_piece(Ks + r * PK + c * PE, kreg[t][u]); }
+                    }
+                    __syncthreads();
+                }
+                if (wave_active) {
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        const int kg = t * 4 + kb;
+                        if (kg < WNKB && kg < nkb_all) {
+#pragma unroll
+                            for (int ks = 0; ks < NKS; ++ks) {
+                                const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kb * 16 + li) * PK + ks * 32 + g * 8);
+                                s[0][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], s[0][kg < WNKB ? kg : 0], 0, 0, 0);
+                                s[1][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], s[1][kg < WNKB ? kg : 0], 0, 0, 0);
+                            }
+                            if (BIAS) {
+                                const half8_t ef = *reinterpret_cast<const half8_t*>(Es + (kg * 16 + li) * PE1 + g * 8);
+                                s[0][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ef, bf[0], s[0][kg < WNKB ? kg : 0], 0, 0, 0);
+                                s[1][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ef, bf[1], s[1][kg < WNKB ? kg : 0], 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
         }
-    }
-    if (!wave_active) return;                           // (no barrier follows)
+        if (!wave_active) return;                           // (the barriers of a following pass are outside this lambda's tail)
 
-    // ---- one-pass softmax in the log2 domain, P^T fragments, O^T = V^T . P^T
-    const float c1 = p.scale * W_LOG2E;
-    f32x4 o[2][ND];
+        // ---- one-pass softmax in the log2 domain, P^T fragments, O^T = V^T . P^T
+        f32x4 o[2][ND];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int n = 0; n < ND; ++n) o[qb][n] = (f32x4)(0.f);
-    float inv_l[2];
-    half8_t pf[2][7];
+            for (int n = 0; n < ND; ++n) o[qb][n] = (f32x4)(0.f);
+        float inv_l[2];
+        half8_t pf[2][7];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        float mx = -INFINITY;
+        for (int qb = 0; qb < 2; ++qb) {
+            float mx = -INFINITY;
 #pragma unroll
-        for (int kg = 0; kg < WNKB; ++kg)
+            for (int kg = 0; kg < WNKB; ++kg)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kg * 16 + g * 4 + r;
-                const float v = key < p.nk ? s[qb][kg][r] * c1 : -INFINITY;
-                s[qb][kg][r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kg * 16 + g * 4 + r;
+                    const float v = key < p.nk ? s[qb][kg][r] * c1 : -INFINITY;
+                    s[qb][kg][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < 14; ++kg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = 0.f;
+                    if (kg < WNKB) { pv = __builtin_amdgcn_exp2f(s[qb][kg < WNKB ? kg : 0][r] - mx); sum += pv; }
+                    // contraction slot (m, g*8 + j): j < 4 -> key block 2m, reg j ; j >= 4 -> key block 2m+1, reg j-4
+                    pf[qb][kg >> 1][(kg & 1) * 4 + r] = (half_t)pv;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            inv_l[qb] = 1.0f / sum;
+        }
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            if (2 * m < nkb_all) {                          // wave-uniform: all P of these 32 keys are exactly 0 otherwise
+#pragma unroll
+                for (int n = 0; n < ND; ++n) {
+                    const half_t* vrow = Vts + (n * 16 + li) * PVF + g * 4;
+                    // key blocks 2m and 2m+1; block 13 does not exist (its P is 0): read block 12 again instead of past the row
+                    const half8_t vf = frag2x4(vrow + (2 * m) * 16, vrow + (m == 6 ? 2 * m : 2 * m + 1) * 16);
+                    o[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][m], o[0][n], 0, 0, 0);
+                    o[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][m], o[1][n], 0, 0, 0);
+                }
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
+        }
+
+        // ---- normalise; lane holds O[query li of qb][d = n*16 + g*4 + r]
 #pragma unroll
-        for (int kg = 0; kg < 14; ++kg)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pv = 0.f;
-                if (kg < WNKB) { pv = __builtin_amdgcn_exp2f(s[qb][kg < WNKB ? kg : 0][r] - mx); sum += pv; }
-                // contraction slot (m, g*8 + j): j < 4 -> key block 2m, reg j ; j >= 4 -> key block 2m+1, reg j-4
-                pf[qb][kg >> 1][(kg & 1) * 4 + r] = (half_t)pv;
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qg = q0 + qb * 16 + li;
+            if (qg >= p.L || ((p.dbg & 4) && o[qb][0][0] != 12345.f)) continue;
+            long row;
+            if (p.win > 0) {
+                const int nw = p.nwx * p.nwy;
+                const int b = s_idx / nw, w = s_idx - b * nw;
+                const int wy = w / p.nwx, wx = w - wy * p.nwx;
+                const int py = qg / p.win, px = qg - py * p.win;
+                const int gy = wy * p.win + py, gx = wx * p.win + px;
+                if (gy >= p.gh || gx >= p.gw) continue;
+                row = (long)b * p.ntok + gy * p.gw + gx;
+            } else {
+                row = (long)s_idx * p.ntok + qg;
             }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        inv_l[qb] = 1.0f / sum;
-    }
-#pragma unroll
-    for (int m = 0; m < 7; ++m) {
-        if (2 * m < nkb_all) {                          // wave-uniform: all P of these 32 keys are exactly 0 otherwise
 #pragma unroll
             for (int n = 0; n < ND; ++n) {
-                const half_t* vrow = Vts + (n * 16 + li) * PVF + g * 4;
-                // key blocks 2m and 2m+1; block 13 does not exist (its P is 0): read block 12 again instead of past the row
-                const half8_t vf = frag2x4(vrow + (2 * m) * 16, vrow + (m == 6 ? 2 * m : 2 * m + 1) * 16);
-                o[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][m], o[0][n], 0, 0, 0);
-                o[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][m], o[1][n], 0, 0, 0);
+                half4_t v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[qb][n][r] * inv_l[qb]);
+                *reinterpret_cast<half4_t*>(out + row * p.D + h * HD + n * 16 + g * 4) = v;
             }
         }
-    }
-
-    // ---- normalise; lane holds O[query li of qb][d = n*16 + g*4 + r]
-    const int s_idx = sh / p.heads, h = sh - s_idx * p.heads;
-    half_t* __restrict__ out = reinterpret_cast<half_t*>(p.out);
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int qg = q0 + qb * 16 + li;
-        if (qg >= p.L || ((p.dbg & 4) && o[qb][0][0] != 12345.f)) continue;
-        long row;
-        if (p.win > 0) {
-            const int nw = p.nwx * p.nwy;
-            const int b = s_idx / nw, w = s_idx - b * nw;
-            const int wy = w / p.nwx, wx = w - wy * p.nwx;
-            const int py = qg / p.win, px = qg - py * p.win;
-            const int gy = wy * p.win + py, gx = wx * p.win + px;
-            if (gy >= p.gh || gx >= p.gw) continue;
-            row = (long)b * p.ntok + gy * p.gw + gx;
-        } else {
-            row = (long)s_idx * p.ntok + qg;
-        }
-#pragma unroll
-        for (int n = 0; n < ND; ++n) {
-            half4_t v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[qb][n][r] * inv_l[qb]);
-            *reinterpret_cast<half4_t*>(out + row * p.D + h * HD + n * 16 + g * 4) = v;
-        }
-    }
+    };
+    run_pass(std::integral_constant<int, 0>{});
+    if (npass > 1) run_pass(std::integral_constant<int, 1>{});
 }
 
 
@@ -356,7 +373,7 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
     }
     if (BIAS) hipLaunchKernelGGL((attnw_prep_kernel<HD>), dim3(8), dim3(256), 0, stream, p.tab_h, p.tab_w, p.KH, p.KW, p.nk,
                                  reinterpret_cast<half_t*>(p.win_prep));
-    dim3 grid((p.L + WQT - 1) / WQT, p.S * p.heads);
+    dim3 grid(p.S * p.heads);                            // one workgroup per (sequence, head); <= 2 query passes inside
     hipLaunchKernelGGL((attnw_kernel<HD, BIAS>), grid, dim3(WNT), lds, stream, p);
     return (int)hipGetLastError();
 }
