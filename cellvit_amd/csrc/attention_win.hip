@@ -178,7 +178,7 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
         constexpr int PS = decltype(passc)::value;
         const int q0 = PS * WQT + wave * WQW;
         const bool wave_active = q0 < p.L && !(p.dbg & 2);
-        if (PS > 0 && wave_active) { load_q(PS); if (BIAS) load_tf(); }   // (the first pass' operands came with the prologue loads)
+        if (PS > 0 && wave_active && BIAS) load_tf();       // (Q of this pass was requested at the end of the previous pass' S loop)
 
         // ---- relcat[q][kh] = q . tab_h[qy - kh + KH - 1] / scale ; relcat[q][KH + kw] likewise (image_encoder.py:347-351);
         // each wave fills and reads back only ITS rows of Rc (LDS is in order per wave: no barrier)
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
             }
         }
         if (!wave_active) return;                           // (the barriers of a following pass are outside this lambda's tail)
+        if (PS == 0 && npass > 1) load_q(1);                // Q of the next pass: in flight during this pass' softmax and PV
 
         // ---- one-pass softmax in the log2 domain, P^T fragments, O^T = V^T . P^T
         f32x4 o[2][ND];
