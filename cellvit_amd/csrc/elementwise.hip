@@ -1,6 +1,8 @@
 // Bandwidth-bound helper kernels — see elementwise.h.
 #include "elementwise.h"
 
+#include <stdlib.h>
+
 namespace cva {
 
 namespace {
@@ -12,7 +14,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // One wave per row, row held in registers (C <= 64*4*MAXV), two-pass mean / variance in fp32.
-template <typename T, int MAXV>
+template <typename T, int MAXV, bool NT = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, long ld_in,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* out_, int out_f32,
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < MAXV; ++i) {
         const int idx = i * 64 + lane;
         if (idx < nv) {
-            v[i] = *reinterpret_cast<const f32x4*>(x + idx * 4);
+            v[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + idx * 4)) : *reinterpret_cast<const f32x4*>(x + idx * 4);
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         } else v[i] = (f32x4)(0.f);
     }
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 if constexpr (sizeof(T) == 2) {      // one 8-byte store per lane (a wave writes 512 contiguous bytes)
                     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
                     const half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
-                    *reinterpret_cast<half4_t*>(o) = h;
+                    if (NT) __builtin_nontemporal_store(h, reinterpret_cast<half4_t*>(o)); else *reinterpret_cast<half4_t*>(o) = h;
                 } else {
                     *reinterpret_cast<f32x4*>(o) = y;
                 }
@@ -196,8 +198,11 @@ int launch_layernorm(const float* in, long ld_in, const float* gamma, const floa
     const dim3 grid((M + 3) / 4), block(256);
     if (C <= 64 * 4 * 2)
         hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
-    else if (C <= 64 * 4 * 5)
-        hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
+    else if (C <= 64 * 4 * 5) {
+        static const int nt = [] { const char* e = getenv("CVA_LN"); return e ? atoi(e) : 1; }();   // 1 (default): nontemporal loads / stores
+        if (nt == 1) hipLaunchKernelGGL((layernorm_kernel<T, 5, true>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
+        else hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
+    }
     else
         hipLaunchKernelGGL((layernorm_kernel<T, 8>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
     return (int)hipGetLastError();
