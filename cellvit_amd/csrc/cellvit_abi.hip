@@ -81,6 +81,9 @@ struct HeadW { float* W = nullptr; float* b = nullptr; int n_out = 0; };
 struct BlockW {
     LNW n1, n2; LinearW qkv, proj, fc1, fc2; bool global = true;
     float* tab_h = nullptr; float* tab_w = nullptr;   // derived (geometry dependent)
+    // window blocks whose token grid is padded: private K / V^T buffers whose pad positions (k = b_k, v = b_v, constant per
+    // layer) are written ONCE when the geometry is set — 0.46 GB per layer at 16 tiles, 13 GB for SAM-H: HBM is there for it
+    void* Kw = nullptr; void* Vtw = nullptr;
 };
 struct BranchW {
     ConvTW up4; ConvW d3[3]; ConvTW up3; ConvW d2[2]; ConvTW up2; ConvW d1[2]; ConvTW up1; ConvW d0[2]; HeadW head;
@@ -370,7 +373,7 @@ int run_convT(const void* src, const ConvTW& w, void* out, int B, int Hs, int Ws
 template <typename T>
 int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, const float* tab_w, bool window,
                         void* Q, void* K, void* Vt, float* relh, float* relw, void* attn_out, int B, int gh, int gw,
-                        int has_cls, int heads, int D, int ws, hipStream_t st) {
+                        int has_cls, int heads, int D, int ws, hipStream_t st, bool prepadded = false) {
     const int hd = D / heads, P = gh * gw, ntok = P + has_cls;
     const int nwy = window ? (gh + ws - 1) / ws : 0, nwx = window ? (gw + ws - 1) / ws : 0;
     const int L = window ? ws * ws : ntok, Lp = round_up(L, 64);
@@ -382,7 +385,7 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
     g.D = D; g.hd = hd; g.heads = heads; g.ntok = ntok; g.L = L; g.Lp = Lp;
     g.win = window ? ws : 0; g.gw = gw; g.gh = gh; g.nwx = nwx; g.nwy = nwy;
     { ProfScope ps(KC_GEMM_QKV, 2.0 * g.M * (double)g.N * g.K, st); CVA_LAUNCH(launch_gemm<T>(g, A_LINEAR, st)); }
-    if (window && (nwy * ws != gh || nwx * ws != gw)) {
+    if (!prepadded && window && (nwy * ws != gh || nwx * ws != gw)) {
         PadKVParams pk{};
         pk.K = K; pk.Vt = Vt; pk.qkv_bias = qkv.bias; pk.B = B; pk.heads = heads; pk.hd = hd; pk.D = D; pk.L = L;
         pk.Lp = Lp; pk.win = ws; pk.gw = gw; pk.gh = gh; pk.nwx = nwx; pk.nwy = nwy;
@@ -439,9 +442,10 @@ int forward_impl(cv_handle* h, const float* x, int B, const cv_outputs* out, hip
         const BlockW& b = h->blocks[i];
         CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n1.g, b.n1.b, h->xn, 0, M, D, LN_EPS, st));
         const bool window = !b.global;
-        CVA_TRY(run_attention_layer<T>(h->xn, b.qkv, b.tab_h, b.tab_w, window, h->Q, h->K,
-                                       window ? h->Vt_win : h->Vt_glob, h->relh, h->relw, h->attn_out, B, g.gh, g.gw,
-                                       g.has_cls, heads, D, c.window_size, st));
+        const bool own_kv = window && b.Kw && b.Vtw;
+        CVA_TRY(run_attention_layer<T>(h->xn, b.qkv, b.tab_h, b.tab_w, window, h->Q, own_kv ? b.Kw : h->K,
+                                       own_kv ? b.Vtw : (window ? h->Vt_win : h->Vt_glob), h->relh, h->relw, h->attn_out, B, g.gh, g.gw,
+                                       g.has_cls, heads, D, c.window_size, st, own_kv));
         CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st));
         CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n2.g, b.n2.b, h->xn, 0, M, D, LN_EPS, st));
         CVA_TRY(run_linear<T>(h->xn, D, b.fc1, nullptr, 0, 0, h->hidden, hid, 0, M, ACT_GELU, st));
@@ -688,7 +692,7 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
     g.Lg = g.ntok; g.Lpg = round_up(g.Lg, 64);
     free_pool(h->ws_allocs);
     h->ws_bytes = 0;
-    for (auto& b : h->blocks) { b.tab_h = b.tab_w = nullptr; }
+    for (auto& b : h->blocks) { b.tab_h = b.tab_w = nullptr; b.Kw = b.Vtw = nullptr; }
     h->pos_table = nullptr;
 
     const int dt = c.compute_dtype;
@@ -710,6 +714,21 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
     CVA_TRY(A(&h->Vt_glob, (size_t)B * heads * hd * g.Lpg * es, true));
     if (c.arch == CV_ARCH_SAM) {
         CVA_TRY(A(&h->Vt_win, (size_t)B * nwin * heads * hd * g.Lpw * es, true));
+        if (g.nwy * c.window_size != g.gh || g.nwx * c.window_size != g.gw) {
+            // padded token grid: one K / V^T pair per window block, pad positions filled now (they are never overwritten:
+            // the qkv epilogue only writes real tokens)
+            for (auto& b : h->blocks) {
+                if (b.global) continue;
+                CVA_TRY(A(&b.Kw, (size_t)B * nwin * heads * g.Lw * hd * es, true));
+                CVA_TRY(A(&b.Vtw, (size_t)B * nwin * heads * hd * g.Lpw * es, true));
+                PadKVParams pk{};
+                pk.K = b.Kw; pk.Vt = b.Vtw; pk.qkv_bias = b.qkv.bias; pk.B = B; pk.heads = heads; pk.hd = hd; pk.D = D; pk.L = g.Lw;
+                pk.Lp = g.Lpw; pk.win = c.window_size; pk.gw = g.gw; pk.gh = g.gh; pk.nwx = g.nwx; pk.nwy = g.nwy;
+                const int rc = dt == CV_DTYPE_F16 ? launch_pad_kv<half_t>(pk, nullptr) : launch_pad_kv<float>(pk, nullptr);
+                if (rc) { cva_set_error("pad_kv launch failed (%d)", rc); return CV_ERR_HIP; }
+            }
+            CVA_CHECK_HIP(hipDeviceSynchronize());
+        }
         const size_t rel_h = std::max((size_t)B * heads * g.Lg * g.gh, (size_t)B * nwin * heads * g.Lw * c.window_size);
         const size_t rel_w = std::max((size_t)B * heads * g.Lg * g.gw, (size_t)B * nwin * heads * g.Lw * c.window_size);
         CVA_TRY(A((void**)&h->relh, rel_h * 4));
