@@ -216,7 +216,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
                     Piece pk; T* e = reinterpret_cast<T*>(&pk);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) e[q] = TR::from_float(v[q]);
-                    store_piece(outT + o, pk);
+                    if (OMODE == OUT_CONVT && !(p.dbg & 1024)) {
+                        // the up-sampled activation (up to 2 GB per launch) is streamed out once and read much later:
+                        // nontemporal, so it does not evict the weights / input panels
+                        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                        const u32x4_t w = {pk.w[0], pk.w[1], pk.w[2], pk.w[3]};
+                        __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(outT + o));
+                    } else {
+                        store_piece(outT + o, pk);
+                    }
                 } else {
                     f32x4 w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
                     *reinterpret_cast<f32x4*>(outT + o) = w0;
