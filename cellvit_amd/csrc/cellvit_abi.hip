@@ -487,8 +487,8 @@ int forward_impl(cv_handle* h, const float* x, int B, const cv_outputs* out, hip
     // ---- shared skip decoders, evaluated ONCE (F9; the reference re-runs them per branch) ----
     const int gh = g.gh, gw = g.gw;
     void *S0 = h->S[0], *S1 = h->S[1], *S2 = h->S[2];
-    CVA_LAUNCH(launch_nchw3_to_nhwc8<T>(x, h->img8, B, H, W, st));
-    CVA_TRY(run_conv3<T>(h->img8, 8, nullptr, 0, h->dec0[0], S0, 0, B, H, W, st));
+    CVA_LAUNCH(launch_nchw3_to_nhwc8<T>(x, h->img8, B, H, W, h->dec0[0].Ctot, st));
+    CVA_TRY(run_conv3<T>(h->img8, h->dec0[0].Ctot, nullptr, 0, h->dec0[0], S0, 0, B, H, W, st));
     CVA_TRY(run_conv3<T>(S0, 32, nullptr, 0, h->dec0[1], h->skip[0], 0, B, H, W, st));
     // decoder1: z1 -> x8
     CVA_TRY(run_convT<T>(h->z[0], h->dec1_t[0], S0, B, gh, gw, st));
@@ -649,7 +649,9 @@ extern "C" int cv_finalize(cv_handle* h) {
         if (c.num_tissue_classes > 0) CVA_TRY(pack_linear(h, "classifier_head", c.num_tissue_classes, C, true, &h->cls_head));
     }
     // shared skip decoders (cellvit.py:116-131)
-    CVA_TRY(pack_conv_block(h, "decoder0.0", 3, 32, &h->dec0[0], 8));
+    // input channels padded to 32 on the fp16 path so that the first conv runs on the halo kernel (whole 32-channel chunks);
+    // 8 on the fp32 parity path (implicit GEMM, 16-byte pieces)
+    CVA_TRY(pack_conv_block(h, "decoder0.0", 3, 32, &h->dec0[0], h->cfg.compute_dtype == CV_DTYPE_F16 ? 32 : 8));
     CVA_TRY(pack_conv_block(h, "decoder0.1", 32, 64, &h->dec0[1]));
     CVA_TRY(pack_deconv_block(h, "decoder1.0", D, s11, &h->dec1_t[0], &h->dec1_c[0]));
     CVA_TRY(pack_deconv_block(h, "decoder1.1", s11, s12, &h->dec1_t[1], &h->dec1_c[1]));
@@ -739,7 +741,7 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
     CVA_TRY(A(&h->attn_out, M * D * es));
     CVA_TRY(A(&h->hidden, M * D * c.mlp_ratio * es));
     for (int j = 0; j < 4; ++j) CVA_TRY(A(&h->z[j], (size_t)B * g.P * D * es));
-    CVA_TRY(A(&h->img8, (size_t)B * H * W * 8 * es));
+    CVA_TRY(A(&h->img8, (size_t)B * H * W * h->dec0[0].Ctot * es));
     const size_t hw = (size_t)H * W;
     CVA_TRY(A(&h->skip[0], (size_t)B * hw * 64 * es));
     CVA_TRY(A(&h->skip[1], (size_t)B * hw / 4 * 128 * es));

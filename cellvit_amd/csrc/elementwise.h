@@ -16,7 +16,7 @@ int launch_layernorm(const float* in, long ld_in, const float* gamma, const floa
 template <typename T> int launch_patchify(const float* x, void* out, int B, int H, int W, hipStream_t stream);
 
 // x fp32 NCHW [B,3,H,W] -> NHWC [B,H,W,8] of T, channels 3..7 zero (decoder0 input, cellvit.py:182,241).
-template <typename T> int launch_nchw3_to_nhwc8(const float* x, void* out, int B, int H, int W, hipStream_t stream);
+template <typename T> int launch_nchw3_to_nhwc8(const float* x, void* out, int B, int H, int W, int CP, hipStream_t stream);
 
 // fp32 token rows -> T rows, optionally dropping a leading cls row per image (cellvit.py:186-189).
 // in: [B, rpi_in, C] (rpi_in = ntok incl. cls); out: [B, ntok_out, C] with ntok_out = rpi_in - skip.

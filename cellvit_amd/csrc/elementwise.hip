@@ -90,16 +90,27 @@ __global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ out
     }
 }
 
+// NCHW fp32 image (3 channels) -> NHWC of T with the channel count padded to CP (8: implicit-GEMM path, 32: the halo
+// convolution kernel, which wants whole 32-channel chunks); one thread per (pixel, 8-channel group)
 template <typename T>
-__global__ void nhwc8_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int H, int W) {
-    const long hw = (long)H * W, total = (long)B * hw;
+__global__ void nhwc8_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int H, int W, int CP) {
+    const long hw = (long)H * W;
+    const int groups = CP >> 3;
+    const long total = (long)B * hw * groups;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long b = i / hw, r = i - b * hw;
-        T* o = out + i * 8;
+        const long pix = i / groups;
+        const int gq = (int)(i - pix * groups);
+        const long b = pix / hw, r = pix - b * hw;
+        T v[8];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = Traits<T>::from_float(x[(b * 3 + c) * hw + r]);
+        for (int c = 0; c < 8; ++c) v[c] = Traits<T>::from_float(0.f);
+        if (gq == 0) {
 #pragma unroll
-        for (int c = 3; c < 8; ++c) o[c] = Traits<T>::from_float(0.f);
+            for (int c = 0; c < 3; ++c) v[c] = Traits<T>::from_float(x[(b * 3 + c) * hw + r]);
+        }
+        T* o = out + pix * CP + gq * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = v[c];
     }
 }
 
@@ -217,9 +228,10 @@ int launch_patchify(const float* x, void* out, int B, int H, int W, hipStream_t 
 }
 
 template <typename T>
-int launch_nchw3_to_nhwc8(const float* x, void* out, int B, int H, int W, hipStream_t stream) {
-    hipLaunchKernelGGL((nhwc8_kernel<T>), dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, x,
-                       reinterpret_cast<T*>(out), B, H, W);
+int launch_nchw3_to_nhwc8(const float* x, void* out, int B, int H, int W, int CP, hipStream_t stream) {
+    if (CP < 8 || (CP & 7)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((nhwc8_kernel<T>), dim3(grid_for((long)B * H * W * (CP >> 3))), dim3(256), 0, stream, x,
+                       reinterpret_cast<T*>(out), B, H, W, CP);
     return (int)hipGetLastError();
 }
 
@@ -267,7 +279,7 @@ int launch_head1x1(const void* feat, const float* Wt, const float* bias, float* 
     template int launch_layernorm<T>(const float*, long, const float*, const float*, void*, int, int, int, float, \
                                      hipStream_t);                                                                \
     template int launch_patchify<T>(const float*, void*, int, int, int, hipStream_t);                             \
-    template int launch_nchw3_to_nhwc8<T>(const float*, void*, int, int, int, hipStream_t);                       \
+    template int launch_nchw3_to_nhwc8<T>(const float*, void*, int, int, int, int, hipStream_t);                       \
     template int launch_cast_tokens<T>(const float*, void*, int, int, int, int, hipStream_t);                     \
     template int launch_cast<T>(const float*, void*, long, hipStream_t);                                          \
     template int launch_head1x1<T>(const void*, const float*, const float*, float*, uint8_t*, int, long, int, int, \
