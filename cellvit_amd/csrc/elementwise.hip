@@ -149,9 +149,21 @@ __global__ void mean_rows_kernel(const float* __restrict__ in, float* __restrict
     // block = (b, 64-channel group); 256 threads = 4 row lanes x 64 channels
     __shared__ float red[4][64];
     const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c < C)
-        for (int r = rl; r < R; r += 4) s += in[((long)b * R + r) * C + c];
+    // 8 independent partial sums per thread keep 8 loads in flight (the single dependent chain made this kernel
+    // latency-bound: 0.14 TB/s on 64 workgroups); fixed summation order -> deterministic
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    if (c < C) {
+        const float* src = in + (long)b * R * C + c;
+        int r = rl;
+        for (; r + 28 < R; r += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += src[(long)(r + 4 * u) * C];
+        }
+        for (; r < R; r += 4) acc[0] += src[(long)r * C];
+    }
+    const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     red[rl][threadIdx.x & 63] = s;
     __syncthreads();
     if (rl == 0 && c < C) out[(long)b * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) +
