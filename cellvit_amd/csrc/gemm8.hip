@@ -171,6 +171,24 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
                     *reinterpret_cast<half8_t*>(o + q * 8) = w;
                 }
             }
+        } else if (OMODE == OUT_CONVT) {
+            // ConvTranspose2d k2 s2: row m = input pixel (b, y, x), column n = (dy*2 + dx) * Cout + co; the lane's 16 columns
+            // are 16 consecutive co of one (dy, dx) (Cout % 16 == 0): one 32-byte run of output pixel (2y + dy, 2x + dx).
+            // The up-sampled activation is streamed out once and read much later: nontemporal stores.
+            const int cout = p.N >> 2;
+            const int dd = n / cout, co = n - dd * cout;
+            const int hw = p.H * p.Wd;
+            const int b = m / hw, r2 = m - b * hw;
+            const int y = r2 / p.Wd, x = r2 - y * p.Wd;
+            half_t* o = reinterpret_cast<half_t*>(p.out) +
+                        (((long)b * 2 * p.H + 2 * y + (dd >> 1)) * (2 * p.Wd) + 2 * x + (dd & 1)) * cout + co;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                half8_t w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
+                __builtin_nontemporal_store(w, reinterpret_cast<half8_t*>(o + q * 8));
+            }
         } else {   // OUT_QKV, q or k columns
             int s_ = tb, pos = tt;
             if (p.win > 0) {
@@ -554,6 +572,7 @@ int launch_gemm8(const GemmParams& p, hipStream_t stream) {
         }
     }
     if (p.out_mode == OUT_QKV) return launch8<OUT_QKV, 1, 0>(p, stream);
+    if ((p.N >> 2) % 16 == 0 && !p.out_f32 && !(p.dbg & 2048)) return launch8<OUT_CONVT, 1, 0>(p, stream);   // direct 32-byte runs
     return launch8<OUT_CONVT, 0, 0>(p, stream);
 }
 
