@@ -96,3 +96,24 @@ def test_attention_short_sequences(B, gh, gw, has_cls, heads, D, win, rel):
     torch.cuda.synchronize()
     ref = _attention_ref(xd.float().cpu(), Wd.float().cpu(), bqkv, tab_h, tab_w, B, gh, gw, has_cls, heads, D, win)
     assert _rel_err(out.float().cpu(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("B,H,W_,Cin,Cout", [(2, 64, 64, 1280, 512), (4, 128, 128, 512, 256), (8, 256, 256, 128, 64)])
+def test_convT2x2_8phase(B, H, W_, Cin, Cout):
+    """ConvTranspose2d k2 s2 at decoder sizes: the GEMM qualifies for the 8-phase kernel and stores the pixel-shuffled
+    output as direct 32-byte runs (transposed accumulators, epilogue8_direct OUT_CONVT)."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, H, W_, Cin, generator=g)
+    Wt = torch.randn(Cin, Cout, 2, 2, generator=g) / math.sqrt(Cin)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xd = _dev(x, F16)
+    Wk = Wt.permute(2, 3, 1, 0).reshape(4 * Cout, Cin).contiguous()   # n = (dy*2+dx)*Cout + co
+    Wd = _dev(Wk, F16)
+    b4 = bias.repeat(4).cuda()
+    out = torch.empty(B, 2 * H, 2 * W_, Cout, device="cuda", dtype=torch.float16)
+    L.check(lib.cv_op_convT2x2(F16, _p(xd), _p(Wd), _p(b4), _p(out), B, H, W_, Cin, Cout, None))
+    torch.cuda.synchronize()
+    Wr = Wd.float().reshape(2, 2, Cout, Cin).permute(3, 2, 0, 1)
+    ref = F.conv_transpose2d(xd.float().permute(0, 3, 1, 2), Wr, bias.cuda(), stride=2).permute(0, 2, 3, 1)
+    assert _rel_err(out.float(), ref) < 2e-3
