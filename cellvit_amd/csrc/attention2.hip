@@ -289,20 +289,27 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
         const int nkb = LAST ? min(4, (p.nk - kt * KT + 15) / 16) : 4;      // key blocks of this tile that hold real keys
 
         // ---- S^T blocks: s[qb][kb][r] = score(query li of qb, key kb*16 + g*4 + r) / scale ----
+        // (k-step outermost: the 8 MFMAs of a k-step write 8 different accumulators, so dependent MFMAs are 8 apart
+        //  instead of 2 — the matrix pipe does not stall on its own result)
         f32x4 s[2][4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            s[0][kb] = (f32x4)(0.f); s[1][kb] = (f32x4)(0.f);
-            if (kb >= nkb) continue;                              // wave-uniform: masked to -inf below
+        for (int kb = 0; kb < 4; ++kb) { s[0][kb] = (f32x4)(0.f); s[1][kb] = (f32x4)(0.f); }
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                if (kb >= nkb) continue;                          // wave-uniform: masked to -inf below
                 const Frag kf = TR::load_frag(Ks + (kb * 16 + li) * PK + ks * 32 + g * 8);
                 TR::mma(kf, qf[0][ks], s[0][kb]);
                 TR::mma(kf, qf[1][ks], s[1][kb]);
             }
-            if (BIAS == 1) {
+        }
+        if (BIAS == 1) {
 #pragma unroll
-                for (int kb2 = 0; kb2 < NBK; ++kb2) {
+            for (int kb2 = 0; kb2 < NBK; ++kb2) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    if (kb >= nkb) continue;
                     const Frag ef = TR::load_frag(Es + (kb * 16 + li) * PE1 + kb2 * 32 + g * 8);
                     TR::mma(ef, bf[0][kb2], s[0][kb]);
                     TR::mma(ef, bf[1][kb2], s[1][kb]);
