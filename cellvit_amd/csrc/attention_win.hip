@@ -236,17 +236,24 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
                     __syncthreads();
                 }
                 if (wave_active) {
+                    // k-step outermost: the MFMAs of one k-step write different accumulators (dependent MFMAs 8 apart)
 #pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) {
-                        const int kg = t * 4 + kb;
-                        if (kg < WNKB && kg < nkb_all) {
+                    for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-                            for (int ks = 0; ks < NKS; ++ks) {
+                        for (int kb = 0; kb < 4; ++kb) {
+                            const int kg = t * 4 + kb;
+                            if (kg < WNKB && kg < nkb_all) {
                                 const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kb * 16 + li) * PK + ks * 32 + g * 8);
                                 s[0][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], s[0][kg < WNKB ? kg : 0], 0, 0, 0);
                                 s[1][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], s[1][kg < WNKB ? kg : 0], 0, 0, 0);
                             }
-                            if (BIAS) {
+                        }
+                    }
+                    if (BIAS) {
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) {
+                            const int kg = t * 4 + kb;
+                            if (kg < WNKB && kg < nkb_all) {
                                 const half8_t ef = *reinterpret_cast<const half8_t*>(Es + (kg * 16 + li) * PE1 + g * 8);
                                 s[0][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ef, bf[0], s[0][kg < WNKB ? kg : 0], 0, 0, 0);
                                 s[1][kg < WNKB ? kg : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ef, bf[1], s[1][kg < WNKB ? kg : 0], 0, 0, 0);
