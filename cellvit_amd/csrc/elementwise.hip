@@ -14,7 +14,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // One wave per row, row held in registers (C <= 64*4*MAXV), two-pass mean / variance in fp32.
-template <typename T, int MAXV, bool NT = false>
+template <typename T, int MAXV, int NT = 0>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, long ld_in,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* out_, int out_f32,
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 if constexpr (sizeof(T) == 2) {      // one 8-byte store per lane (a wave writes 512 contiguous bytes)
                     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
                     const half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
-                    if (NT) __builtin_nontemporal_store(h, reinterpret_cast<half4_t*>(o)); else *reinterpret_cast<half4_t*>(o) = h;
+                    if (NT == 1) __builtin_nontemporal_store(h, reinterpret_cast<half4_t*>(o)); else *reinterpret_cast<half4_t*>(o) = h;
                 } else {
                     *reinterpret_cast<f32x4*>(o) = y;
                 }
@@ -223,7 +223,8 @@ int launch_layernorm(const float* in, long ld_in, const float* gamma, const floa
         hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
     else if (C <= 64 * 4 * 5) {
         static const int nt = [] { const char* e = getenv("CVA_LN"); return e ? atoi(e) : 1; }();   // 1 (default): nontemporal loads / stores
-        if (nt == 1) hipLaunchKernelGGL((layernorm_kernel<T, 5, true>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
+        if (nt == 2) hipLaunchKernelGGL((layernorm_kernel<T, 5, 2>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
+        else if (nt == 1) hipLaunchKernelGGL((layernorm_kernel<T, 5, 1>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
         else hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
     }
     else
