@@ -144,3 +144,23 @@ def test_samh_1024_fp16_full_size_properties():
         assert d < ATOL_F16, (k, d)
     agree = (a["nuclei_type_map"][0].argmax(0) == out1["nuclei_type_map"][0].argmax(0)).float().mean().item()
     assert agree > 0.995, agree
+
+
+@pytest.mark.parametrize("tile,B", [(512, 4), (256, 16)])
+def test_samh_fp16_vs_fp32_engine_other_geometries(tile, B):
+    """Geometries other than 1024^2 (different window padding, rel-pos bias variants, contraction-kernel eligibility):
+    the production fp16 engine against the exact-fp32 engine of the same library on the same batch."""
+    from cellvit_amd.spec import cellvit_sam_config
+    from cellvit_amd.weights import make_state_dict, normalize_tile, synthetic_tile_u8
+    cfg = cellvit_sam_config("SAM-H")
+    sd = make_state_dict(cfg, seed=0)
+    x = torch.from_numpy(np.stack([normalize_tile(synthetic_tile_u8(i, size=tile, he_like=True)) for i in range(B)])).cuda()
+    m16, m32 = _model(cfg, sd, "fp16"), _model(cfg, sd, "fp32")
+    a = m16(x, retrieve_tokens=True)
+    b = m32(x, retrieve_tokens=True)
+    torch.cuda.synchronize()
+    for k in ("tissue_types", "nuclei_binary_map", "hv_map", "nuclei_type_map"):
+        d = (a[k].float() - b[k].float()).abs().max().item()
+        assert d < ATOL_F16, (k, d)
+    agree = (a["nuclei_type_map"].argmax(1) == b["nuclei_type_map"].argmax(1)).float().mean().item()
+    assert agree > 0.99, agree
