@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 namespace cva {
 
@@ -347,6 +348,378 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
 }
 
 
+// ---- persistent variant for the two-pass case (128 < L <= 208: the 196-position SAM windows) -----------------------
+// One workgroup of 8 waves per CU walks (window, head) items grid-stride; wave w owns queries 32w .. 32w+31, so an
+// item is ONE pass.  K of item i+1 is DMA'd (global_load_lds) into the second K image and its V^T pieces are requested
+// into registers right after item i's LDS image is complete, so both land while item i computes; Q of item i+1 is
+// requested when item i's S loop has consumed its Q fragments.  Every wave retires its own loads (vmcnt(0)) BEFORE it
+// issues the item's output stores, so store drain is never waited for.  E and the fp16 tables are staged once per
+// workgroup.  All of K is resident in LDS (pitch hd + 8: conflict-free b128 fragment reads), so the key loop has no
+// barriers: two barriers per item in total.
+constexpr int PNT = 512;
+
+__device__ __forceinline__ const unsigned char* uniform_ptr_w(const void* q) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+}
+// global -> LDS DMA of 64 x 16 B; M0 = LDS byte address of the 1-KiB destination (no other code here depends on M0)
+#define AW_DMA(voff, base, ldsaddr)                                                                         \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), \
+                 "s"(ldsaddr) : "memory")
+
+#define AW_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define AW_DSR2(dst, addr, o0, o1) asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"(o1))
+#define AW_WAIT(n)                                                                                          \
+    do {                                                                                                    \
+        half8_t &r0_ = ring[0], &r1_ = ring[1], &r2_ = ring[2], &r3_ = ring[3];                            \
+        asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r0_), "+v"(r1_), "+v"(r2_), "+v"(r3_) :: "memory"); \
+    } while (0)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int HD>
+struct AttnwpGeom {
+    static constexpr int HDP = (HD + 31) / 32 * 32;
+    static constexpr int KPPR = HD / 8;                 // pieces per K row in memory
+    static constexpr int LPPR = KPPR + 1;               // ... and in LDS (row pitch hd + 8 halves)
+    static constexpr int NDMA = (WKEYS * LPPR + 63) / 64;
+    static constexpr int KROWS = (NDMA * 64 + LPPR - 1) / LPPR;
+    static constexpr int KIMG = KROWS * (HD + 8);       // halves per K image
+    static constexpr size_t lds_bytes() {
+        return (size_t)(2 * KIMG + HD * (WKEYS + 4) + WKEYS * 40 + (PNT / 64) * WQW * 40 + 64 * (HDP + 8)) * sizeof(half_t);
+    }
+};
+
+template <int HD, int BIAS>
+__global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
+    using GM = AttnwpGeom<HD>;
+    constexpr int PE = 8;
+    constexpr int HDP = GM::HDP, NKS = HDP / 32, ND = HD / 16;
+    constexpr int PKP = HD + 8;                         // K row pitch (176 B for hd 80); the last k-step of hd 80 reads the pad piece
+                                                        // and 8 columns of the NEXT row (both finite) against zero Q fragments
+    constexpr int PVF = WKEYS + 4;                      // as in attnw_kernel
+    constexpr int PE1 = 32 + 8;
+    constexpr int PT = HDP + 8;                         // table row pitch (208 B for hd 80)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemw[];
+    half_t* Ks0 = reinterpret_cast<half_t*>(smemw);     // 2 x [KROWS][PKP]
+    half_t* Vts = Ks0 + 2 * GM::KIMG;                   // [HD][PVF]
+    half_t* Es = Vts + HD * PVF;                        // [208][PE1]
+    half_t* Rc = Es + WKEYS * PE1;                      // [256][PE1]
+    half_t* Ts = Rc + (PNT / 64) * WQW * PE1;           // [64][PT]
+    const unsigned ldsK = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smemw;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g_ = lane >> 4, li_ = lane & 15;
+    const int nitems = p.S * p.heads;
+    const half_t* __restrict__ Qb = reinterpret_cast<const half_t*>(p.Q);
+    const half_t* __restrict__ Kb = reinterpret_cast<const half_t*>(p.K);
+    const half_t* __restrict__ Vb = reinterpret_cast<const half_t*>(p.Vt);
+    half_t* __restrict__ out = reinterpret_cast<half_t*>(p.out);
+
+    // ---- once per workgroup: zero the V^T image (pad columns and keys past nk stay zero for good), stage E and the tables
+    for (int i = tid; i < HD * PVF / 4; i += PNT) reinterpret_cast<unsigned long long*>(Vts)[i] = 0ull;
+    for (int i = tid; i < (PNT / 64) * WQW * PE1 / PE; i += PNT) store_piece(Rc + i * PE, zero_piece());
+    if (BIAS) {
+        const half_t* __restrict__ prepE = reinterpret_cast<const half_t*>(p.win_prep);
+        const half_t* __restrict__ prepT = prepE + WKEYS * 32;
+        for (int i = tid; i < WKEYS * 4; i += PNT) store_piece(Es + (i >> 2) * PE1 + (i & 3) * PE, load_piece(prepE + i * PE));
+        for (int i = tid; i < 64 * (HDP / PE); i += PNT) {
+            const int r = i / (HDP / PE), c = i - r * (HDP / PE);
+            store_piece(Ts + r * PT + c * PE, load_piece(prepT + r * HDP + c * PE));
+        }
+    }
+
+    // ---- K: DMA piece j of the LDS image <- row min(j / LPPR, nk-1), piece min(j % LPPR, KPPR-1) (clamped: finite data;
+    // keys past nk are masked in the softmax, the pad piece only meets zero Q fragments)
+    constexpr int DPW = (GM::NDMA + 7) / 8;             // DMA instructions per wave
+    unsigned kvoff[DPW];
+#pragma unroll
+    for (int t = 0; t < DPW; ++t) {
+        const int j = (wave + 8 * t) * 64 + lane;
+        int r = j / GM::LPPR, c = j - r * GM::LPPR;
+        r = r < p.nk ? r : p.nk - 1;
+        c = c < GM::KPPR ? c : GM::KPPR - 1;
+        kvoff[t] = (unsigned)(r * HD + c * PE) * 2u;
+    }
+    auto dma_k = [&](int sh, int buf) {
+        const unsigned char* base = uniform_ptr_w(Kb + (long)sh * p.L * HD);
+#pragma unroll
+        for (int t = 0; t < DPW; ++t) {
+            const int u = wave + 8 * t;
+            if (u < GM::NDMA) {                          // wave-uniform
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ldsK + (unsigned)buf * (GM::KIMG * 2) + (unsigned)u * 1024u);
+                AW_DMA(kvoff[t], base, dst);
+            }
+        }
+    };
+
+    constexpr int VPPR = WKEYS / PE;                    // 26 pieces per V^T row
+    constexpr int VN = (HD * VPPR + PNT - 1) / PNT;
+    Piece vreg[VN];
+    half8_t qf[2][NKS];
+    const int q0 = wave * WQW;
+    const bool wave_active = q0 < p.L;
+
+    auto load_v = [&](int sh) {
+        const half_t* __restrict__ Vg = Vb + (long)sh * HD * p.Lp;
+#pragma unroll
+        for (int u = 0; u < VN; ++u) {
+            const int i = tid + u * PNT;
+            const int d = i / VPPR, c = i - d * VPPR;
+            vreg[u] = (i < HD * VPPR && c * PE < p.nk) ? load_piece(Vg + (long)d * p.Lp + c * PE) : zero_piece();
+        }
+    };
+    auto store_v = [&]() {
+#pragma unroll
+        for (int u = 0; u < VN; ++u) {
+            const int i = tid + u * PNT;
+            const int d = i / VPPR, c = i - d * VPPR;
+            const int key0 = c * PE;
+            if (i < HD * VPPR && key0 < p.nk) {
+                Piece v = vreg[u];
+                if (key0 + PE > p.nk) {                 // elements past the last key meet P = 0 but must not be NaN
+                    half_t* e = reinterpret_cast<half_t*>(&v);
+#pragma unroll
+                    for (int j = 0; j < PE; ++j) if (key0 + j >= p.nk) e[j] = (half_t)0.f;
+                }
+                unsigned long long* dst = reinterpret_cast<unsigned long long*>(Vts + d * PVF + c * PE);   // two 8-byte stores
+                dst[0] = ((unsigned long long)v.w[1] << 32) | v.w[0];
+                dst[1] = ((unsigned long long)v.w[3] << 32) | v.w[2];
+            }
+        }
+    };
+    auto load_q = [&](int sh) {
+        const half_t* __restrict__ Qg = Qb + (long)sh * p.L * HD;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int row = q0 + qb * 16 + li_;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int d0 = ks * 32 + g_ * 8;
+                qf[qb][ks] = (row < p.L && d0 < HD) ? *reinterpret_cast<const half8_t*>(Qg + (long)row * HD + d0) : (half8_t)(0);
+            }
+        }
+    };
+
+    const float c1 = p.scale * W_LOG2E;
+    int it = blockIdx.x;
+    int buf = 0;
+    if (it < nitems) { dma_k(it, 0); load_v(it); load_q(it); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // zero fill / E / tables / K image 0 complete
+
+    for (; it < nitems; it += gridDim.x, buf ^= 1) {
+        const half_t* Ks = Ks0 + buf * GM::KIMG;
+        store_v();
+        __syncthreads();                                // V^T of this item visible (its K image was fenced by the previous barrier)
+        const int nxt = it + gridDim.x;
+        if (nxt < nitems) { dma_k(nxt, buf ^ 1); load_v(nxt); }   // in flight during this item's compute
+
+        // Loop-invariant per-lane predicates and addresses (key < nk, the rel-pos scatter conditions, ...) would be hoisted
+        // out of the item loop and cost > 100 SGPRs / VGPRs of live state: re-derive them per item from opaque copies.
+        int nk = p.nk, li = li_, g = g_;
+        asm volatile("" : "+s"(nk));
+        asm volatile("" : "+v"(li), "+v"(g));
+        if (wave_active) {
+            // ---- relcat rows of this wave's queries (see attnw_kernel)
+            half8_t bf[2];
+            if (BIAS) {
+                // (every column < KH + KW of a valid query's row is rewritten per item; the rest of Rc was zeroed once.  Writes
+                // that fall outside the band go to the row's never-read pad column 32: no divergent stores)
+                half_t* myrc = Rc + (wave * WQW) * PE1;
+                const float inv_scale = 1.0f / p.scale;
+#pragma unroll
+                for (int tbl = 0; tbl < 2; ++tbl) {
+                    const int Ksz = tbl == 0 ? p.KH : p.KW;
+                    const int off = tbl == 0 ? 0 : p.KH;
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        half8_t tfr[NKS];
+#pragma unroll
+                        for (int ks = 0; ks < NKS; ++ks)
+                            tfr[ks] = *reinterpret_cast<const half8_t*>(Ts + (tbl * 32 + jb * 16 + li) * PT + ks * 32 + g * 8);
+#pragma unroll
+                        for (int qb = 0; qb < 2; ++qb) {
+                            f32x4 acc = (f32x4)(0.f);
+#pragma unroll
+                            for (int ks = 0; ks < NKS; ++ks)
+                                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfr[ks], qf[qb][ks], acc, 0, 0, 0);
+                            const int q = q0 + qb * 16 + li;
+                            const int qy = q / p.KW, qx = q - qy * p.KW;
+                            const int c = (tbl == 0 ? qy : qx) + Ksz - 1 - jb * 16 - g * 4;
+                            half_t* rrow = myrc + (qb * 16 + li) * PE1;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int kk = c - r;               // 0 <= kk < Ksz implies a valid table row jj < 2 Ksz - 1
+                                const bool ok = (unsigned)kk < (unsigned)Ksz && q < p.L;
+                                rrow[ok ? off + kk : 32] = (half_t)(acc[r] * inv_scale);
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) bf[qb] = *reinterpret_cast<const half8_t*>(myrc + (qb * 16 + li) * PE1 + g * 8);
+            }
+
+            // ---- S^T for all 13 key blocks (rows past nk hold finite clamped data and are masked below), k-step outermost,
+            // then the rel-pos contraction against E.  Fragment reads run 4 steps ahead of their MFMAs through a register
+            // ring (inline-asm ds_read + counted lgkmcnt: left to itself the compiler issues each read right before its use).
+            f32x4 s[2][WNKB];
+#pragma unroll
+            for (int kg = 0; kg < WNKB; ++kg) { s[0][kg] = (f32x4)(0.f); s[1][kg] = (f32x4)(0.f); }
+            half8_t ring[4];
+            {
+                const unsigned kbase = ldsK + (unsigned)buf * (GM::KIMG * 2) + (unsigned)(li * PKP + g * 8) * 2u;
+                const unsigned ebase = ldsK + (unsigned)(2 * GM::KIMG + HD * PVF) * 2u + (unsigned)(li * PE1 + g * 8) * 2u;
+                constexpr int TK = NKS * WNKB, TS = TK + (BIAS ? WNKB : 0);
+                auto rd = [&](auto tc) {                    // fragment of step t: K block kg, k-step ks  |  E block t - TK
+                    constexpr int t = decltype(tc)::value;
+                    half8_t& dst = ring[t & 3];             // (named here: asm operands alone do not capture)
+                    const unsigned kb = kbase, eb = ebase;
+                    if constexpr (t < TK) { constexpr int ks = t / WNKB, kg = t - ks * WNKB; AW_DSR128(dst, kb, (kg * 16 * PKP + ks * 32) * 2); }
+                    else AW_DSR128(dst, eb, (t - TK) * 16 * PE1 * 2);
+                };
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                static_for<4>(rd);
+                static_for<TS>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    constexpr int left = TS - 1 - t;        // reads issued after this step's
+                    if constexpr (left >= 3) AW_WAIT(3); else if constexpr (left == 2) AW_WAIT(2); else if constexpr (left == 1) AW_WAIT(1); else AW_WAIT(0);
+                    if constexpr (t < TK) {
+                        constexpr int ks = t / WNKB, kg = t - ks * WNKB;
+                        s[0][kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[t & 3], qf[0][ks], s[0][kg], 0, 0, 0);
+                        s[1][kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[t & 3], qf[1][ks], s[1][kg], 0, 0, 0);
+                    } else {
+                        constexpr int kg = t - TK;
+                        s[0][kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[t & 3], bf[0], s[0][kg], 0, 0, 0);
+                        s[1][kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[t & 3], bf[1], s[1][kg], 0, 0, 0);
+                    }
+                    if constexpr (t + 4 < TS) rd(std::integral_constant<int, t + 4>{});
+                    __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs between their wait and the ring refill
+                });
+            }
+            if (nxt < nitems) load_q(nxt);              // Q of the next item: in flight during the softmax and PV
+
+            // ---- one-pass softmax in the log2 domain, P^T fragments, O^T = V^T . P^T
+            f32x4 o[2][ND];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int n = 0; n < ND; ++n) o[qb][n] = (f32x4)(0.f);
+            float inv_l[2];
+            half8_t pf[2][7];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                // nk > 192 on this path: only the last key block has keys to mask.  p = 2^(s c1 - max c1) as ONE packed fma per
+                // pair (the maximum is taken over the raw scores, c1 > 0)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((WNKB - 1) * 16 + g * 4 + r >= nk) s[qb][WNKB - 1][r] = -INFINITY;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kg = 0; kg < WNKB; ++kg)           // max(a, b) = med3(a, b, +inf): no IEEE-mode canonicalisation of the MFMA results
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = __builtin_amdgcn_fmed3f(mx, s[qb][kg][r], INFINITY);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const f32x2 c2 = {c1, c1};
+                const f32x2 m2 = {-mx * c1, -mx * c1};
+                f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+                for (int kg = 0; kg < 14; ++kg) {
+                    if (kg < WNKB) {
+                        const int kq = kg < WNKB ? kg : 0;
+                        const f32x2 a0 = {s[qb][kq][0], s[qb][kq][1]}, a1 = {s[qb][kq][2], s[qb][kq][3]};
+                        const f32x2 e0 = __builtin_elementwise_fma(a0, c2, m2), e1 = __builtin_elementwise_fma(a1, c2, m2);
+                        f32x2 p0, p1;
+                        p0[0] = __builtin_amdgcn_exp2f(e0[0]); p0[1] = __builtin_amdgcn_exp2f(e0[1]);
+                        p1[0] = __builtin_amdgcn_exp2f(e1[0]); p1[1] = __builtin_amdgcn_exp2f(e1[1]);
+                        sum2 += p0; sum2 += p1;
+                        // contraction slot (m, g*8 + j): j < 4 -> key block 2m, reg j ; j >= 4 -> key block 2m+1, reg j-4
+                        pf[qb][kg >> 1][(kg & 1) * 4 + 0] = (half_t)p0[0]; pf[qb][kg >> 1][(kg & 1) * 4 + 1] = (half_t)p0[1];
+                        pf[qb][kg >> 1][(kg & 1) * 4 + 2] = (half_t)p1[0]; pf[qb][kg >> 1][(kg & 1) * 4 + 3] = (half_t)p1[1];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pf[qb][kg >> 1][(kg & 1) * 4 + r] = (half_t)0.f;
+                    }
+                }
+                float sum = sum2[0] + sum2[1];
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                inv_l[qb] = 1.0f / sum;
+            }
+            {
+                // V^T fragments: key blocks 2m and 2m+1 of row n*16 + li (two 8-byte halves, 32 B apart); block 13 does not
+                // exist (its P is 0): block 12 is read again instead.  Same 4-deep ring as above.
+                unsigned vb[ND];
+#pragma unroll
+                for (int n = 0; n < ND; ++n) vb[n] = ldsK + (unsigned)(2 * GM::KIMG) * 2u + (unsigned)((n * 16 + li) * PVF + g * 4) * 2u;
+                constexpr int TP = 7 * ND;
+                auto rd = [&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    constexpr int m = t / ND, n = t - m * ND;
+                    half8_t& dst = ring[t & 3];
+                    const unsigned va = vb[n];
+                    AW_DSR2(dst, va, m * 8, m == 6 ? m * 8 : m * 8 + 4);
+                };
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                static_for<4>(rd);
+                static_for<TP>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    constexpr int m = t / ND, n = t - m * ND;
+                    constexpr int left = TP - 1 - t;
+                    if constexpr (left >= 3) AW_WAIT(3); else if constexpr (left == 2) AW_WAIT(2); else if constexpr (left == 1) AW_WAIT(1); else AW_WAIT(0);
+                    o[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[t & 3], pf[0][m], o[0][n], 0, 0, 0);
+                    o[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[t & 3], pf[1][m], o[1][n], 0, 0, 0);
+                    if constexpr (t + 4 < TP) rd(std::integral_constant<int, t + 4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+
+            // ---- normalise and store; lane holds O[query li of qb][d = n*16 + g*4 + r].  This wave's prefetches (K DMA,
+            // V^T, Q of the next item) are retired first: nothing ever waits for the stores below
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int s_idx = it / p.heads, h = it - s_idx * p.heads;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const int qg = q0 + qb * 16 + li;
+                if (qg >= p.L) continue;
+                long row;
+                if (p.win > 0) {
+                    const int nw = p.nwx * p.nwy;
+                    const int b = s_idx / nw, w = s_idx - b * nw;
+                    const int wy = w / p.nwx, wx = w - wy * p.nwx;
+                    const int py = qg / p.win, px = qg - py * p.win;
+                    const int gy = wy * p.win + py, gx = wx * p.win + px;
+                    if (gy >= p.gh || gx >= p.gw) continue;
+                    row = (long)b * p.ntok + gy * p.gw + gx;
+                } else {
+                    row = (long)s_idx * p.ntok + qg;
+                }
+#pragma unroll
+                for (int n = 0; n < ND; ++n) {
+                    half4_t v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[qb][n][r] * inv_l[qb]);
+                    *reinterpret_cast<half4_t*>(out + row * p.D + h * HD + n * 16 + g * 4) = v;
+                }
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                // every wave is done with this item's K / V^T; the next K image has landed
+    }
+}
+
+
 // E and the fp16 tables, once per layer (they are the same for every workgroup of the layer)
 template <int HD>
 __global__ void attnw_prep_kernel(const float* __restrict__ tab_h, const float* __restrict__ tab_w, int KH, int KW, int nk,
@@ -381,6 +754,27 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
     }
     if (BIAS) hipLaunchKernelGGL((attnw_prep_kernel<HD>), dim3(8), dim3(256), 0, stream, p.tab_h, p.tab_w, p.KH, p.KW, p.nk,
                                  reinterpret_cast<half_t*>(p.win_prep));
+    static int persistent = -1;
+    if (persistent < 0) { const char* e = getenv("CVA_ATTNW_P"); persistent = e ? atoi(e) : 1; }
+    if (BIAS && persistent && p.nk > (WNKB - 1) * 16 && p.S * p.heads >= 64) {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 256;
+        }
+        static bool attr_p = false;
+        if (!attr_p) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attnwp_kernel<HD, BIAS>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_p = true;
+        }
+        const size_t ldsp = AttnwpGeom<HD>::lds_bytes();
+        const int items = p.S * p.heads;
+        hipLaunchKernelGGL((attnwp_kernel<HD, BIAS>), dim3(items < n_cu ? items : n_cu), dim3(PNT), ldsp, stream, p);
+        return (int)hipGetLastError();
+    }
     dim3 grid(p.S * p.heads);                            // one workgroup per (sequence, head); <= 2 query passes inside
     hipLaunchKernelGGL((attnw_kernel<HD, BIAS>), grid, dim3(WNT), lds, stream, p);
     return (int)hipGetLastError();
