@@ -17,6 +17,7 @@ def main():
     M, N, K = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (16384, 5120, 1280)
     iters = int(sys.argv[4]) if len(sys.argv) >= 5 else 20
     lib = _lib.load()
+    act = int(os.environ.get("ACT", "0"))
     g = torch.Generator(device="cuda").manual_seed(0)
     A = (torch.rand(M, K, device="cuda", generator=g) * 2 - 1).half()
     W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / K ** 0.5).half()
@@ -24,12 +25,12 @@ def main():
     out = torch.empty(M, N, device="cuda", dtype=torch.float16)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     for _ in range(3):
-        _lib.check(lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, 0, None))
+        _lib.check(lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, act, None))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, 0, None)
+        lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, act, None)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
@@ -37,13 +38,15 @@ def main():
     err = 0.0
     for r0 in range(0, M, 4096):
         ref = A[r0:r0 + 4096].float() @ W.float().t()
+        if act == 1:
+            ref = torch.nn.functional.gelu(ref)
         err = max(err, float((out[r0:r0 + 4096].float() - ref).abs().max()))
     first = out.clone()
     nrace = int(os.environ.get("RACE", "5"))
     bad = 0
     for _ in range(nrace):
         out.zero_()
-        lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, 0, None)
+        lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, act, None)
         torch.cuda.synchronize()
         bad += int((out != first).sum().item())
     if bad:
