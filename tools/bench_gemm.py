@@ -18,19 +18,22 @@ def main():
     iters = int(sys.argv[4]) if len(sys.argv) >= 5 else 20
     lib = _lib.load()
     act = int(os.environ.get("ACT", "0"))
+    use_res = int(os.environ.get("RES", "0"))
     g = torch.Generator(device="cuda").manual_seed(0)
     A = (torch.rand(M, K, device="cuda", generator=g) * 2 - 1).half()
     W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / K ** 0.5).half()
     b = torch.zeros(N, device="cuda")
-    out = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32 if use_res else torch.float16)
+    res = torch.randn(M, N, device="cuda") if use_res else None
+    pr = C.c_void_p(res.data_ptr()) if use_res else None
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     for _ in range(3):
-        _lib.check(lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, act, None))
+        _lib.check(lib.cv_op_linear(0, p(A), p(W), p(b), pr, p(out), use_res, M, N, K, act, None))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, act, None)
+        lib.cv_op_linear(0, p(A), p(W), p(b), pr, p(out), use_res, M, N, K, act, None)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
@@ -40,13 +43,15 @@ def main():
         ref = A[r0:r0 + 4096].float() @ W.float().t()
         if act == 1:
             ref = torch.nn.functional.gelu(ref)
+        if use_res:
+            ref = ref + res[r0:r0 + 4096]
         err = max(err, float((out[r0:r0 + 4096].float() - ref).abs().max()))
     first = out.clone()
     nrace = int(os.environ.get("RACE", "5"))
     bad = 0
     for _ in range(nrace):
         out.zero_()
-        lib.cv_op_linear(0, p(A), p(W), p(b), None, p(out), 0, M, N, K, act, None)
+        lib.cv_op_linear(0, p(A), p(W), p(b), pr, p(out), use_res, M, N, K, act, None)
         torch.cuda.synchronize()
         bad += int((out != first).sum().item())
     if bad:
