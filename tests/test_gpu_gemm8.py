@@ -73,7 +73,8 @@ def test_attention_qkv_8phase(B, gh, gw, heads, D, win):
     (2, 14, 14, 1, 6, 384, 0, False),     # 197 keys (cls token), ragged last key block
     (1, 28, 28, 0, 12, 768, 14, True),    # SAM-B windows, hd 64, rel-pos -> attnw_kernel<64, 1>
     (1, 14, 14, 0, 16, 1280, 0, False),   # hd 80, no bias              -> attnw_kernel<80, 0>
-    (1, 30, 30, 0, 16, 1280, 14, True),   # SAM-H windows with padded edge windows (30 -> 42)
+    (1, 30, 30, 0, 16, 1280, 14, True),   # SAM-H windows with padded edge windows (30 -> 42) -> attnwp_kernel<80, 1>
+    (2, 28, 28, 0, 12, 768, 14, True),    # 96 (window, head) items of hd 64 -> persistent attnwp_kernel<64, 1>
 ])
 def test_attention_short_sequences(B, gh, gw, has_cls, heads, D, win, rel):
     """fp16 sequences of <= 208 keys run the single-pass window kernel (attention_win.hip)."""
@@ -117,3 +118,34 @@ def test_convT2x2_8phase(B, H, W_, Cin, Cout):
     Wr = Wd.float().reshape(2, 2, Cout, Cin).permute(3, 2, 0, 1)
     ref = F.conv_transpose2d(xd.float().permute(0, 3, 1, 2), Wr, bias.cuda(), stride=2).permute(0, 2, 3, 1)
     assert _rel_err(out.float(), ref) < 2e-3
+
+
+def test_window_attention_persistent_many_items_and_race_screen():
+    """8 tiles of 64x64 tokens = 3200 (window, head) items on 256 persistent workgroups (12-13 items each, both K images
+    and the register prefetch in steady state): checked against the reference, and repeated launches must reproduce the
+    first result bit for bit (the kernel hand-counts vmcnt / lgkmcnt)."""
+    L, lib = _lib()
+    B, gh, gw, heads, D, win = 8, 64, 64, 16, 1280, 14
+    g = torch.Generator().manual_seed(11)
+    hd = D // heads
+    ntok = gh * gw
+    x = torch.randn(B * ntok, D, generator=g)
+    Wqkv = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
+    bqkv = torch.randn(3 * D, generator=g) * 0.3
+    tab_h = torch.randn(2 * win - 1, hd, generator=g) * 0.2
+    tab_w = torch.randn(2 * win - 1, hd, generator=g) * 0.2
+    xd, Wd = _dev(x, F16), _dev(Wqkv, F16)
+    bd, thd, twd = bqkv.cuda(), tab_h.cuda(), tab_w.cuda()
+    outs = []
+    for _ in range(4):
+        out = torch.zeros(B * ntok, D, device="cuda", dtype=torch.float16)
+        L.check(lib.cv_op_attention(F16, _p(xd), _p(Wd), _p(bd), _p(thd), _p(twd), _p(out), B, gh, gw, 0, heads, D, win, None))
+        torch.cuda.synchronize()
+        outs.append(out)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    # reference on two of the eight tiles (the CPU reference is O(tokens^2) per window only, but 8 tiles take a while)
+    for b in (0, 7):
+        sl = slice(b * ntok, (b + 1) * ntok)
+        ref = _attention_ref(xd[sl].float().cpu(), Wd.float().cpu(), bqkv, tab_h, tab_w, 1, gh, gw, 0, heads, D, win)
+        assert _rel_err(outs[0][sl].float().cpu(), ref) < 1e-2
