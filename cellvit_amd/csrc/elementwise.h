@@ -10,6 +10,9 @@ namespace cva {
 template <typename T>
 int launch_layernorm(const float* in, long ld_in, const float* gamma, const float* beta, void* out,
                      int out_f32, int M, int C, float eps, hipStream_t stream);
+// fp16 engine: x_io[M, C] (fp32, row stride ld) += delta[M, C] (fp16); out[M, C] (fp16, may alias delta) = LayerNorm(x_io)
+int launch_layernorm_add(float* x_io, long ld, const void* delta, const float* gamma, const float* beta, void* out,
+                         int M, int C, float eps, hipStream_t stream);
 
 // x fp32 NCHW [B,3,H,W] -> patch matrix [B*(H/16)*(W/16), 768] of T, k = c*256 + ky*16 + kx
 // (the flattening of Conv2d(3, D, 16, 16).weight — vits_histo.py:273-280, image_encoder.py:418-426).

@@ -119,6 +119,10 @@ int cv_op_linear(int dtype, const void* A, const void* W, const float* bias, con
                  void* out, int out_f32, int M, int N, int K, int act, void* stream);
 int cv_op_layernorm(int dtype, const float* x, const float* gamma, const float* beta, void* out,
                     int out_f32, int M, int C, float eps, void* stream);
+/* fp16 engine: x_io[M,C] (fp32) += delta[M,C] (fp16, the projection's output); out[M,C] (fp16, may alias delta) =
+ * LayerNorm(x_io).  The residual add of vits_histo.py:236 / image_encoder.py:182 fused into the norm that follows it.   */
+int cv_op_layernorm_add(float* x_io, const void* delta_f16, const float* gamma, const float* beta, void* out_f16,
+                        int M, int C, float eps, void* stream);
 /* NHWC 3x3 conv (pad 1) over the channel concat of src1 (C1) and src2 (C2, may be NULL/0);
  * Wk: [Cout, 9*(C1+C2)] of `dtype`, k = tap*(C1+C2) + c; bias fp32 [Cout] or NULL.                     */
 int cv_op_conv3x3(int dtype, const void* src1, int C1, const void* src2, int C2, const void* Wk,

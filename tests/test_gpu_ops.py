@@ -76,6 +76,25 @@ def test_layernorm_rows(dtype, M, Cc):
     assert _rel_err(out.float().cpu(), ref) < (1e-5 if dtype == F32 else 1e-3)
 
 
+@pytest.mark.parametrize("M,Cc,alias", [(257, 384, False), (100, 1280, True), (4096, 1280, True), (5, 768, False)])
+def test_layernorm_add_rows(M, Cc, alias):
+    """residual add fused into the following LayerNorm (fp16 engine): x += delta; out = LN(x); out may alias delta."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, Cc, generator=g) * 3 + 0.5
+    d = (torch.randn(M, Cc, generator=g) * 0.7).half()
+    w = torch.rand(Cc, generator=g) + 0.5
+    b = torch.randn(Cc, generator=g) * 0.1
+    xd, dd, wd, bd = x.cuda(), d.cuda(), w.cuda(), b.cuda()
+    out = dd if alias else torch.empty(M, Cc, device="cuda", dtype=torch.float16)
+    L.check(lib.cv_op_layernorm_add(_p(xd), _p(dd), _p(wd), _p(bd), _p(out), M, Cc, 1e-6, None))
+    torch.cuda.synchronize()
+    xs = x + d.float()
+    assert torch.equal(xd.cpu(), xs)                       # the fp32 stream is updated exactly
+    ref = F.layer_norm(xs, (Cc,), w, b, 1e-6)
+    assert _rel_err(out.float().cpu(), ref) < 1e-3
+
+
 def _pack_conv(W):  # [Cout, Cin, 3, 3] -> [Cout, 9*Cin], k = tap*Cin + c
     Cout, Cin = W.shape[:2]
     return W.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
