@@ -569,7 +569,13 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
             // ---- ordered flood ----
-            while (n > 0) {
+            // The entries pushed by a pop are appended one iteration LATE: their distance values are requested with the
+            // claim, and the next iteration first scans the existing pool (LDS latency + compares) before it touches
+            // them — the global-memory round trip of dist[q] overlaps the scan instead of preceding it.  The deferred
+            // entries take part in that iteration's minimum from registers, so the pop order is unchanged.
+            bool pend = false; double pend_v = 0; int pend_q = 0, pend_lab = 0; unsigned pend_age = 0;
+            int npend = 0;
+            while (n > 0 || npend > 0) {
                 Key2 best; best.hi = ~0ull; best.lo = ~0ull;
                 for (int sl = lane; sl < n; sl += 64) {
                     Key2 k;
@@ -577,6 +583,18 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                     else { const long o = ovf_base + (sl - POOL_LDS); k.hi = ohi[o]; k.lo = olo[o]; }
                     k.lo |= (u64)sl;
                     if (key_less(k, best)) best = k;
+                }
+                if (npend > 0) {
+                    const u64 pm = __ballot(pend);
+                    const int slot = n + __popcll(pm & ((1ull << lane) - 1ull));
+                    append(pend, pend_v, pend_age, pend_q, pend_lab);      // n += npend
+                    if (pend) {
+                        Key2 k; k.hi = sortable_f64(pend_v);
+                        k.lo = ((u64)pend_age << 42) | ((u64)(unsigned)pend_q << 20) | (u64)slot;
+                        if (key_less(k, best)) best = k;
+                    }
+                    npend = 0; pend = false;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
                 best = wave_min_key(best);
                 // winner: identical on all lanes
@@ -601,7 +619,7 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                     const int yy = py + dy, xx = px + dx;
                     if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
                         q = yy * W + xx;
-                        qv = (p.dbg & 1) ? (double)(q & 1023) : dist[q];   // issued together with the claim
+                        qv = dist[q];                                     // consumed after the NEXT iteration's pool scan
                         if (use_bits) {
                             if (yy >= by0 && yy <= by1 && xx >= bx0 && xx <= bx1) {
                                 const int loc = (yy - by0) * bw + (xx - bx0);
@@ -615,11 +633,11 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                     }
                 }
                 const u64 m = __ballot(have);
-                const unsigned myage = age + 1u + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the hole fill above precedes the appends
-                append(have, qv, myage, q, plab);
-                age += (unsigned)__popcll(m);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                pend = have; pend_v = qv; pend_q = q; pend_lab = plab;
+                pend_age = age + 1u + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                npend = __popcll(m);
+                age += (unsigned)npend;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the hole fill precedes the next scan
             }
         }
     }
