@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One *step* = one batch of B (default 16) synthetic 1024x1024 tiles through the whole hot path:
+One *step* = one batch of B (default 32) synthetic 1024x1024 tiles through the whole hot path:
   forward (ViT encoder + shared skips + 3 decoder branches, HIP)  ->  on-device Sobel / marker
   watershed post-processing up to the per-tile instance records (HIP).
 Inputs (normalised fp32 tiles; synthetic nucleus maps for the post-processing leg) are resident in
@@ -39,9 +39,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16,
-                    help="tiles per step per GPU (the reference CLI default batch_size is 8; 16 makes the token count 256 row\n"
-                         "tiles = one per CU, so every linear layer tiles the chip without a partial round)")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="tiles per step per GPU (the reference CLI default batch_size is 8; multiples of 16 make the token count a\n"
+                         "multiple of 256 row tiles = one per CU, so every linear layer tiles the chip without a partial round;\n"
+                         "32 measured +1.8 %% over 16 in one run: fewer per-launch tails, post-processing tail amortised)")
     ap.add_argument("--model", default="samh", choices=["samh", "vit256"])
     ap.add_argument("--tile", type=int, default=1024)
     ap.add_argument("--cells", type=int, default=800, help="synthetic nuclei per 1024^2 tile (post-proc input)")

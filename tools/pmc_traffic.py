@@ -58,9 +58,7 @@ def main():
                 out[BENCH_KEYS[key]] = f2 + w
     out["_detail_MiB_per_launch"] = detail
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    old = json.load(open(path)) if os.path.exists(path) else {}
-    if "_algorithmic_MiB_per_launch_B16" in old:
-        out["_algorithmic_MiB_per_launch_B16"] = old["_algorithmic_MiB_per_launch_B16"]
+    out["_tiles_per_step"] = "bench.py default (--batch)"
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(detail, indent=1))
 
