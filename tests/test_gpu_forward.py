@@ -144,6 +144,22 @@ def test_samh_1024_fp16_full_size_properties():
         assert d < ATOL_F16, (k, d)
     agree = (a["nuclei_type_map"][0].argmax(0) == out1["nuclei_type_map"][0].argmax(0)).float().mean().item()
     assert agree > 0.995, agree
+    # bench.py's default batch (32 tiles: decoder activations of 8.6 GB, i.e. byte offsets far beyond 32 bits): the LAST and a
+    # middle tile of the batch must reproduce the small-batch results of the same tiles
+    keep = {k: (out1[k][0].clone(), a[k][1].clone()) for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map")}
+    del out1, a, b
+    x32 = x2[1:2].repeat(32, 1, 1, 1)
+    x32[31] = x2[0]
+    x32[17] = x2[0]
+    big = m(x32)
+    torch.cuda.synchronize()
+    for k, (gold_tile, other_tile) in keep.items():
+        for idx, ref in ((31, gold_tile), (17, gold_tile), (0, other_tile), (30, other_tile)):
+            d = (big[k][idx] - ref).abs().max().item()
+            assert d < ATOL_F16, (k, idx, d)
+    for idx in (17, 31):
+        agree = (big["nuclei_type_map"][idx].argmax(0) == keep["nuclei_type_map"][0].argmax(0)).float().mean().item()
+        assert agree > 0.995, (idx, agree)
 
 
 @pytest.mark.parametrize("tile,B", [(512, 4), (256, 16)])
