@@ -99,6 +99,27 @@ def test_batch_of_different_tiles():
         _assert_dicts_equal(dicts[i], o_d)
 
 
+def test_batch_of_32_full_tiles_matches_single_tile_runs():
+    """bench.py's default batch: 32 tiles of 1024^2 in one launch chain (per-tile bases far apart, one flood queue per
+    tile) reproduce the single-tile results bit for bit — first, middle and last tile."""
+    m0 = synth_nuclei_maps(40, 1024, 500)
+    m1 = synth_nuclei_maps(41, 1024, 900)
+    singles = []
+    for m in (m0, m1):
+        inst, dicts, _ = _gpu_chain(m[0][None], m[1][None], m[2][None], 40)
+        singles.append((inst[0].copy(), dicts[0]))
+    order = [0] * 32
+    for i in (13, 31):
+        order[i] = 1
+    maps = (m0, m1)
+    tm = np.stack([maps[o][0] for o in order]); bm = np.stack([maps[o][1] for o in order]); hv = np.stack([maps[o][2] for o in order])
+    inst, dicts, _ = _gpu_chain(tm, bm, hv, 40)
+    for i in (0, 13, 30, 31):
+        ref_inst, ref_d = singles[order[i]]
+        assert np.array_equal(inst[i], ref_inst), i
+        _assert_dicts_equal(dicts[i], ref_d)
+
+
 def test_dense_tile_large_components_overflow_pool():
     """Heavily overlapping nuclei -> few huge mask components: exercises the LDS-pool overflow arena."""
     from oracle import postproc_ref as P
