@@ -4,12 +4,15 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--model samh|vit256]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches those N ranks itself (re-exec under
+torch.distributed.run on 127.0.0.1), one process per GPU over RCCL.
 
 One *step* = one batch of B (default 32) synthetic 1024x1024 tiles through the whole hot path:
-  forward (ViT encoder + shared skips + 3 decoder branches, HIP)  ->  on-device Sobel / marker
-  watershed post-processing up to the per-tile instance records (HIP).
-Inputs (normalised fp32 tiles; synthetic nucleus maps for the post-processing leg) are resident in
-HBM before the timed region.  `value` = whole-job 1024x1024 tiles/s (BASELINE.json metric).
+  raw uint8 tiles -> inference transform fused into the forward's loaders (cv_forward_u8) -> forward (ViT encoder +
+  shared skips + 3 decoder branches, HIP)  ->  on-device Sobel / marker watershed post-processing up to the per-tile
+  instance records (HIP).
+Inputs (raw u8 tiles; synthetic nucleus maps for the post-processing leg) are resident in HBM before the timed
+region.  `value` = whole-job 1024x1024 tiles/s (BASELINE.json metric).
 Tiles shard across ranks with no data-path collective (weak scaling: B tiles per rank per step).
 
 Post-processing input: random-weight logits are salt-and-pepper and contain no nuclei, so — as
@@ -49,21 +52,35 @@ def parse():
     ap.add_argument("--no-postproc", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--allow-debug-env", action="store_true", help="run although CVA_* experiment switches are set (recorded in config)")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f8"],
+                    help="f8: CDNA4 MX-fp8 MFMA for the encoder's linear layers, fp16 attention core and decoder (BASELINE.json configs[4])")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run post-processing on the forward stream instead of a second HIP stream")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, tile, cells, n_threads=None):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores, one tile."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, sd, tile, cells, with_8_threads=True):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores, one tile: forward with all
+    the threads torch takes by default and with 8 threads; post-processing single-threaded as the
+    reference runs it.  ~25 s + ~35 s of CPU work on the GPU box."""
     import numpy as np
     import torch
     from cellvit_amd.synth import synth_nuclei_maps
     from cellvit_amd.weights import normalize_tile, synthetic_tile_u8
     from oracle import forward_ref, postproc_ref
-    if n_threads:
-        torch.set_num_threads(n_threads)
     x = torch.from_numpy(normalize_tile(synthetic_tile_u8(0, size=tile, he_like=True)))[None]
+    n_all = int(torch.get_num_threads())
     t0 = time.perf_counter()
     forward_ref.forward(x, sd, cfg, retrieve_tokens=True)
     t_fwd = time.perf_counter() - t0
@@ -72,14 +89,51 @@ def cpu_baseline(cfg, sd, tile, cells, n_threads=None):
     t0 = time.perf_counter()
     postproc_ref.postprocess_tile(pm, 6, 40)
     t_pp = time.perf_counter() - t0
-    return {"value": 1.0 / (t_fwd + t_pp), "unit": "tiles/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"1 tile {tile}x{tile}: oracle forward (torch fp32, {torch.get_num_threads()} threads) "
-                      f"{t_fwd:.2f} s + oracle post-proc (C, 1 thread) {t_pp:.3f} s",
-            "forward_s": t_fwd, "postproc_s": t_pp}
+    out = {"value": 1.0 / (t_fwd + t_pp), "unit": "tiles/s", "cores": n_all, "kind": "port",
+           "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(),
+           "sample": f"1 tile {tile}x{tile}: oracle forward (torch fp32, {n_all} threads) "
+                     f"{t_fwd:.2f} s + oracle post-proc (C, 1 thread) {t_pp:.3f} s",
+           "forward_s": t_fwd, "postproc_s": t_pp}
+    if with_8_threads and n_all != 8:
+        torch.set_num_threads(8)
+        t0 = time.perf_counter()
+        forward_ref.forward(x, sd, cfg, retrieve_tokens=True)
+        t8 = time.perf_counter() - t0
+        torch.set_num_threads(n_all)
+        out["threads8"] = {"value": 1.0 / (t8 + t_pp), "unit": "tiles/s", "cores": 8, "forward_s": t8}
+    return out
+
+
+def debug_env():
+    """CVA_* variables are experiment switches of ABLATION builds of the library (some skip parts of kernels)."""
+    return sorted(k for k in os.environ if k.startswith("CVA_"))
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` outside a launcher: run the N ranks ourselves, one process per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] --gpus {n} without a launcher: spawning {n} ranks via torch.distributed.run (RCCL, 127.0.0.1:{port})",
+          file=sys.stderr)
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    dbg = debug_env()
+    if dbg and not args.allow_debug_env:
+        print(f"bench.py: refusing to run with experiment switches in the environment: {dbg} "
+              "(they select ablation code paths in -DCVA_ABLATION builds; unset them or pass --allow-debug-env)", file=sys.stderr)
+        sys.exit(3)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -87,9 +141,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rank == 0:
+            print(f"[bench] {dist.get_world_size()} ranks on backend {dist.get_backend()} (RCCL)", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -100,23 +159,31 @@ def main():
     from cellvit_amd.synth import synth_nuclei_maps
     from cellvit_amd.weights import make_state_dict, normalize_tile, synthetic_tile_u8
 
+    if _lib.load().cv_build_is_ablation():
+        print("bench.py: libcellvit_amd.so is an ABLATION build (-DCVA_ABLATION); rebuild with `python -m cellvit_amd.build`",
+              file=sys.stderr)
+        sys.exit(3)
+    cdt = "fp16" if args.dtype == "f16" else "fp8"
     if args.model == "samh":
         cfg = cellvit_sam_config("SAM-H")
-        model = CellViTSAM(None, 6, 19, "SAM-H", compute_dtype="fp16")
+        model = CellViTSAM(None, 6, 19, "SAM-H", compute_dtype=cdt)
         workload = ("CellViT-SAM-H fp16, 1024x1024 tiles, full on-GPU fwd + Sobel/watershed postproc "
-                    "(BASELINE.json configs[2])")
+                    "(BASELINE.json configs[2])") if args.dtype == "f16" else \
+                   ("CellViT-SAM-H MX-fp8 encoder linear layers + fp16 attention core / decoder, 1024x1024 tiles, full on-GPU fwd + "
+                    "postproc (BASELINE.json configs[4])")
         flops_per_tile = 9.50e12 * (args.tile / 1024.0) ** 2      # SURVEY §8d algorithmic FLOPs
     else:
         cfg = cellvit256_config()
-        model = CellViT256(None, 6, 19, compute_dtype="fp16")
+        model = CellViT256(None, 6, 19, compute_dtype=cdt)
         workload = "CellViT-256 fp16, 1024x1024 tiles, fwd + on-GPU postproc (BASELINE.json configs[1] + postproc)"
         flops_per_tile = 3.38e12 * (args.tile / 1024.0) ** 2
     sd = make_state_dict(cfg, seed=0)
     model.load_state_dict(sd)
 
     B, T = args.batch, args.tile
-    x = torch.from_numpy(np.stack([normalize_tile(synthetic_tile_u8(rank * B + i, size=T, he_like=True))
-                                   for i in range(B)])).to(dev)
+    # raw uint8 HWC tiles, as the decode workers of the CLI hand them over; mean = std = 0.5 (reference default, :214-227)
+    x = torch.from_numpy(np.stack([synthetic_tile_u8(rank * B + i, size=T, he_like=True) for i in range(B)])).to(dev)
+    MEAN = STD = (0.5, 0.5, 0.5)
     do_pp = not args.no_postproc
     if do_pp:
         maps = [synth_nuclei_maps(rank * B + i, T, args.cells) for i in range(B)]
@@ -131,7 +198,7 @@ def main():
     def step():
         """forward on the main stream; post-processing of the SAME step on a second stream (it is a
         latency-bound chain that occupies few CUs, so it overlaps the next step's forward)."""
-        out = model(x, retrieve_tokens=True)
+        out = model.forward_u8(x, MEAN, STD, retrieve_tokens=True)
         res = None
         if do_pp:
             if overlap:
@@ -150,7 +217,7 @@ def main():
     # per-stage times from one sequential (non-overlapped) step outside the timed region
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e[0].record()
-    model(x, retrieve_tokens=True)
+    model.forward_u8(x, MEAN, STD, retrieve_tokens=True)
     e[1].record()
     if do_pp:
         postprocess_device(pp_bin, pp_type, pp_hv, 6, 10, 21, want_contours=True)
@@ -202,13 +269,18 @@ def main():
             roofline = {"bound": "mfma", "kernel": KCLASS[dom], "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS,
                         "flops_per_launch": fl[dom] / n[dom], "avg_launch_us": 1e3 * ms[dom] / n[dom],
-                        "launches": int(n[dom]), "traffic": traffic}
+                        "launches": int(n[dom]), "traffic": traffic,
+                        "traffic_source": "profiles/traffic_latest.json: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, "
+                                          "corrected per MI355X_MICROARCH.md (tools/pmc_traffic.py); not collected in this run"
+                                          if traffic is not None else None}
         rec = {
             "metric": METRIC, "value": world * B * args.steps / dt, "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "tile": T, "tiles_per_step_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"tile-sharded x{world}, no data-path collective",
+                       "input": "raw uint8 HWC tiles resident in HBM; inference transform fused into the forward (cv_forward_u8)",
+                       "experiment_env": dbg,
                        "postproc": bool(do_pp), "postproc_stream_overlap": bool(overlap), "postproc_input": f"synthetic nuclei maps, {args.cells} cells/tile",
                        "instances_per_step": n_inst},
             "stage_ms_sequential": {"forward": fwd_ms, "postproc": pp_ms},

@@ -37,6 +37,7 @@ class cv_outputs(C.Structure):
 # name -> (restype, argtypes); the CPU test suite checks that every one of these resolves.
 SYMBOLS = {
     "cv_last_error": (C.c_char_p, []),
+    "cv_build_is_ablation": (C.c_int, []),
     "cv_create": (C.c_int, [C.POINTER(cv_config), C.POINTER(C.c_void_p)]),
     "cv_destroy": (C.c_int, [C.c_void_p]),
     "cv_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
@@ -44,6 +45,13 @@ SYMBOLS = {
     "cv_set_geometry": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "cv_set_derived": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "cv_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(cv_outputs), C.c_void_p]),
+    "cv_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
+                                C.POINTER(cv_outputs), C.c_void_p]),
+    "cv_op_argmax_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cv_op_normalize_u8": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p]),
+    "cv_pool_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "cv_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
     "cv_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "cv_op_linear": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -78,6 +86,13 @@ class cv_instance(C.Structure):
                 ("npix", C.c_int32), ("type", C.c_int32), ("contour_off", C.c_int32), ("contour_len", C.c_int32),
                 ("reserved", C.c_int32), ("cx", C.c_double), ("cy", C.c_double), ("type_prob", C.c_double)]
 
+
+# numpy view of a cv_instance array copied from the device (64 bytes per record)
+import numpy as _np  # noqa: E402
+REC_DTYPE = _np.dtype([("id", "<i4"), ("rmin", "<i4"), ("cmin", "<i4"), ("rmax", "<i4"), ("cmax", "<i4"), ("npix", "<i4"),
+                       ("type", "<i4"), ("contour_off", "<i4"), ("contour_len", "<i4"), ("reserved", "<i4"),
+                       ("cx", "<f8"), ("cy", "<f8"), ("type_prob", "<f8")])
+assert REC_DTYPE.itemsize == C.sizeof(cv_instance)
 
 _lib = None
 

@@ -36,9 +36,17 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> str:
+    """ablation=True adds -DCVA_ABLATION (CVA_* experiment switches honoured; never used by bench.py / tests)."""
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
+    flags = FLAGS + (["-DCVA_ABLATION"] if ablation else [])
+    stamp = os.path.join(OBJ, ".flavour")
+    flavour = "ablation" if ablation else "production"
+    if not os.path.exists(stamp) or open(stamp).read().strip() != flavour:
+        force = True
+        with open(stamp, "w") as f:
+            f.write(flavour)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cellvit_amd.h"))
     jobs = []
@@ -49,7 +57,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
@@ -72,4 +80,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, ablation="--ablation" in sys.argv)

@@ -754,8 +754,7 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
     }
     if (BIAS) hipLaunchKernelGGL((attnw_prep_kernel<HD>), dim3(8), dim3(256), 0, stream, p.tab_h, p.tab_w, p.KH, p.KW, p.nk,
                                  reinterpret_cast<half_t*>(p.win_prep));
-    static int persistent = -1;
-    if (persistent < 0) { const char* e = getenv("CVA_ATTNW_P"); persistent = e ? atoi(e) : 1; }
+    static const int persistent = cva_env_int("CVA_ATTNW_P", 1);
     if (BIAS && persistent && p.nk > (WNKB - 1) * 16 && p.S * p.heads >= 64) {
         static int n_cu = 0;
         if (!n_cu) {
@@ -785,7 +784,7 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
 // fp16 only; returns -1 when the geometry is not covered (caller uses attention2)
 int launch_attention_win(const AttnParams& p_in, hipStream_t stream) {
     AttnParams p = p_in;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CVA_ATTNW_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+    { static const int dbg = cva_env_int("CVA_ATTNW_DBG", 0); p.dbg = dbg; }   // ablation builds only
     if (p.nk > WKEYS || p.nk != p.L || p.Lp < WKEYS) return -1;
     const bool bias = p.tab_h && p.tab_w;
     if (bias && (p.KH > 16 || p.KW > 16 || p.nk != p.KH * p.KW || !p.win_prep)) return -1;

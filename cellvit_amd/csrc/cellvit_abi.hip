@@ -25,6 +25,7 @@ void cva_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* cv_last_error(void) { return g_err; }
+extern "C" int cv_build_is_ablation(void) { return cva::CVA_ABLATION_BUILD; }
 
 using namespace cva;
 
@@ -125,7 +126,7 @@ struct cv_handle {
     size_t ws_bytes = 0;
     int last_B = 0;
     Profiler prof;
-    bool no_ln_add = getenv("CVA_LN_ADD") && atoi(getenv("CVA_LN_ADD")) == 0;   // A/B switch: residual add in the proj epilogue
+    bool no_ln_add = cva::cva_env_int("CVA_LN_ADD", 1) == 0;   // A/B switch (ablation builds): residual add in the proj epilogue
 };
 
 namespace {
@@ -337,10 +338,10 @@ int run_conv3(const void* s1, int C1, const void* s2, int C2, const ConvW& w, vo
     p.out_mode = OUT_LINEAR; p.out_f32 = out_f32; p.out = out; p.ldc = w.Cout;
     ProfScope ps(KC_CONV3, 2.0 * p.M * (double)w.Cout * 9.0 * w.Cin_real, st);
     if (sizeof(T) == 2) {   // fp16 production path: halo-tiled direct convolution where the layer fits it
-        static const int conv_variant = [] { const char* e = getenv("CVA_CONV"); return e ? atoi(e) : 2; }();
+        static const int conv_variant = cva_env_int("CVA_CONV", 2);
         if (conv_variant != 1) {
             p.zero = gemm_zero_page();
-            static const int head_fuse = [] { const char* e = getenv("CVA_HEADFUSE"); return e ? atoi(e) : 1; }();
+            static const int head_fuse = cva_env_int("CVA_HEADFUSE", 1);
             if (head && head_fuse && head->nout <= 8 && w.Cout == 64) {
                 p.head_W = head->W; p.head_b = head->b; p.head_logits = head->logits; p.head_argmax = head->argmax;
                 p.head_nout = head->nout; p.head_narg = head->narg;
@@ -398,7 +399,7 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
     a.S = S; a.heads = heads; a.L = L; a.Lp = Lp; a.hd = hd; a.D = D; a.nk = L; a.KH = KH; a.KW = KW;
     a.scale = 1.0f / std::sqrt((float)hd);
     a.ntok = ntok; a.win = window ? ws : 0; a.gw = gw; a.gh = gh; a.nwx = nwx; a.nwy = nwy;
-    static const int attn_variant = [] { const char* e = getenv("CVA_ATTN"); return e ? atoi(e) : 3; }();   // 3: window kernel + v2, 2: v2 only, 1: v1
+    static const int attn_variant = cva_env_int("CVA_ATTN", 3);   // 3: window kernel + v2, 2: v2 only, 1: v1
     if (attn_variant != 1) {
         a.tab_h = tab_h; a.tab_w = tab_w;
         ProfScope ps(KC_ATTN, 4.0 * (double)B * P * (window ? L : ntok) * hd * heads + (window ? 0.0 : 4.0 * B * has_cls * (double)ntok * hd * heads), st);
@@ -423,7 +424,7 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
 }
 
 template <typename T>
-int forward_impl(cv_handle* h, const float* x, int B, const cv_outputs* out, hipStream_t st) {
+int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const cv_outputs* out, hipStream_t st) {
     const cv_config& c = h->cfg;
     const Geometry& g = h->g;
     const int D = c.embed_dim, heads = c.num_heads, H = g.H, W = g.W, P = g.P, ntok = g.ntok;
@@ -431,7 +432,7 @@ int forward_impl(cv_handle* h, const float* x, int B, const cv_outputs* out, hip
     int s11, s12, bott; skip_dims(c, &s11, &s12, &bott);
 
     // ---- patch embedding + positional table (F1/F2/F2') ----
-    CVA_LAUNCH(launch_patchify<T>(x, h->patchA, B, H, W, st));
+    CVA_LAUNCH(launch_patchify<T>(x, u8, h->patchA, B, H, W, st));
     CVA_TRY(run_linear<T>(h->patchA, 768, h->patch, h->pos_table + (size_t)g.has_cls * D, D, P, h->resid, D, 1,
                           B * P, ACT_NONE, st, g.has_cls ? P : 0, g.has_cls, g.has_cls));
     if (g.has_cls) CVA_LAUNCH(launch_cls_rows(h->cls_token, h->pos_table, h->resid, B, ntok, D, st));
@@ -498,7 +499,7 @@ int forward_impl(cv_handle* h, const float* x, int B, const cv_outputs* out, hip
     // ---- shared skip decoders, evaluated ONCE (F9; the reference re-runs them per branch) ----
     const int gh = g.gh, gw = g.gw;
     void *S0 = h->S[0], *S1 = h->S[1], *S2 = h->S[2];
-    CVA_LAUNCH(launch_nchw3_to_nhwc8<T>(x, h->img8, B, H, W, h->dec0[0].Ctot, st));
+    CVA_LAUNCH(launch_nchw3_to_nhwc8<T>(x, u8, h->img8, B, H, W, h->dec0[0].Ctot, st));
     CVA_TRY(run_conv3<T>(h->img8, h->dec0[0].Ctot, nullptr, 0, h->dec0[0], S0, 0, B, H, W, st));
     CVA_TRY(run_conv3<T>(S0, 32, nullptr, 0, h->dec0[1], h->skip[0], 0, B, H, W, st));
     // decoder1: z1 -> x8
@@ -811,8 +812,9 @@ extern "C" int cv_set_derived(cv_handle* h, const char* name, const float* host_
     return CV_ERR_INVALID;
 }
 
-extern "C" int cv_forward(cv_handle* h, const float* x_dev, int B, int H, int W, const cv_outputs* out, void* stream) {
-    if (!h || !x_dev || !out) { cva_set_error("null argument"); return CV_ERR_INVALID; }
+static int forward_checked(cv_handle* h, const float* x_dev, const InputU8* u8, int B, int H, int W, const cv_outputs* out,
+                           void* stream) {
+    if (!h || (!x_dev && !u8) || !out) { cva_set_error("null argument"); return CV_ERR_INVALID; }
     if (!h->finalized) { cva_set_error("cv_forward before cv_finalize"); return CV_ERR_STATE; }
     if (H % h->cfg.patch_size != 0 || W % h->cfg.patch_size != 0) {
         cva_set_error("Img must have a shape of that is divisible by patch_size (token_size)");
@@ -828,10 +830,27 @@ extern "C" int cv_forward(cv_handle* h, const float* x_dev, int B, int H, int W,
             if (!h->blocks[i].tab_h || !h->blocks[i].tab_w) { cva_set_error("derived rel-pos tables of block %d not set", i); return CV_ERR_STATE; }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     g_prof = &h->prof;
-    const int rc = h->cfg.compute_dtype == CV_DTYPE_F16 ? forward_impl<half_t>(h, x_dev, B, out, st)
-                                                         : forward_impl<float>(h, x_dev, B, out, st);
+    const int rc = h->cfg.compute_dtype == CV_DTYPE_F16 ? forward_impl<half_t>(h, x_dev, u8, B, out, st)
+                                                         : forward_impl<float>(h, x_dev, u8, B, out, st);
     g_prof = nullptr;
     return rc;
+}
+
+extern "C" int cv_forward(cv_handle* h, const float* x_dev, int B, int H, int W, const cv_outputs* out, void* stream) {
+    if (!x_dev) { cva_set_error("null argument"); return CV_ERR_INVALID; }
+    return forward_checked(h, x_dev, nullptr, B, H, W, out, stream);
+}
+
+extern "C" int cv_forward_u8(cv_handle* h, const uint8_t* x_u8, const float* mean3, const float* std3, int B, int H, int W,
+                             const cv_outputs* out, void* stream) {
+    if (!x_u8 || !mean3 || !std3) { cva_set_error("null argument"); return CV_ERR_INVALID; }
+    InputU8 u8{};
+    u8.x = x_u8;
+    for (int c = 0; c < 3; ++c) {
+        if (!(std3[c] != 0.f)) { cva_set_error("std must be non-zero"); return CV_ERR_INVALID; }
+        u8.mean[c] = mean3[c]; u8.stdv[c] = std3[c];
+    }
+    return forward_checked(h, nullptr, &u8, B, H, W, out, stream);
 }
 
 extern "C" int cv_set_debug(cv_handle* h, int enable) {
@@ -963,6 +982,36 @@ extern "C" int cv_op_attention(int dtype, const void* x, const void* Wqkv, const
     if (hipStreamSynchronize(st) != hipSuccess && !rc) { cva_set_error("attention: stream sync failed: %s", hipGetErrorString(hipGetLastError())); rc = CV_ERR_HIP; }
     free_pool(pool);
     return rc;
+}
+
+extern "C" int cv_op_argmax_nchw(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream) {
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    const int rc = launch_argmax_nchw(x, out, B, C, (long)H * W, reinterpret_cast<hipStream_t>(stream));
+    if (rc) { cva_set_error("argmax launch failed (%d)", rc); return rc == (int)hipErrorInvalidValue ? CV_ERR_INVALID : CV_ERR_HIP; }
+    return CV_OK;
+}
+
+extern "C" int cv_op_normalize_u8(const uint8_t* x_u8, const float* mean3, const float* std3, float* out, int B, int H, int W,
+                                  void* stream) {
+    if (!x_u8 || !mean3 || !std3 || !out || B <= 0 || H <= 0 || W <= 0) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    InputU8 u8{};
+    u8.x = x_u8;
+    for (int c = 0; c < 3; ++c) { u8.mean[c] = mean3[c]; u8.stdv[c] = std3[c]; }
+    const int rc = launch_normalize_u8(u8, out, B, (long)H * W, reinterpret_cast<hipStream_t>(stream));
+    if (rc) { cva_set_error("normalize launch failed (%d)", rc); return CV_ERR_HIP; }
+    return CV_OK;
+}
+
+extern "C" int cv_pool_tokens(const float* tokens_nhwc, int B, int gh, int gw, int D, int patch_size, const cv_instance* recs,
+                              int max_inst, const int32_t* n_recs, const int64_t* rec_offset, int max_n, float* out,
+                              void* stream) {
+    if (!tokens_nhwc || !recs || !n_recs || !rec_offset || !out || B <= 0 || gh <= 0 || gw <= 0 || D <= 0 || patch_size <= 0 ||
+        max_inst <= 0 || max_n < 0) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    const int rc = launch_pool_tokens(tokens_nhwc, recs, (int)sizeof(cv_instance), max_inst, n_recs, rec_offset, B,
+                                      max_n < max_inst ? max_n : max_inst, gh, gw, D, patch_size, out,
+                                      reinterpret_cast<hipStream_t>(stream));
+    if (rc) { cva_set_error("pool_tokens launch failed (%d)", rc); return CV_ERR_HIP; }
+    return CV_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace cva {
 
@@ -10,6 +11,17 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WAVE = 64;
+
+// Experiment switches (kernel-variant A/B selectors and *_DBG ablations that SKIP parts of a kernel) exist only in a
+// library built with -DCVA_ABLATION (python -m cellvit_amd.build --ablation).  The production library ignores the
+// environment altogether: a timed region can not be one variable away from skipping work.
+#ifdef CVA_ABLATION
+inline int cva_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+constexpr int CVA_ABLATION_BUILD = 1;
+#else
+inline int cva_env_int(const char*, int dflt) { return dflt; }
+constexpr int CVA_ABLATION_BUILD = 0;
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Storage-type traits.  T = half_t is the production path (fp16 storage, fp32 MFMA accumulate,

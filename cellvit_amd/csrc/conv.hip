@@ -277,8 +277,7 @@ int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
     else if (((size_t)p.out & 15) != 0 || !p.out) return -1;
     static int occ = -1;
     if (occ < 0) {
-        const char* e = getenv("CVA_CONV_OCC");
-        occ = e ? atoi(e) : 2;
+        occ = cva_env_int("CVA_CONV_OCC", 2);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,

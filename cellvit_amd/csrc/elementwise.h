@@ -16,10 +16,23 @@ int launch_layernorm_add(float* x_io, long ld, const void* delta, const float* g
 
 // x fp32 NCHW [B,3,H,W] -> patch matrix [B*(H/16)*(W/16), 768] of T, k = c*256 + ky*16 + kx
 // (the flattening of Conv2d(3, D, 16, 16).weight — vits_histo.py:273-280, image_encoder.py:418-426).
-template <typename T> int launch_patchify(const float* x, void* out, int B, int H, int W, hipStream_t stream);
+// Raw-tile input (F0 fused): x uint8 NHWC [B,H,W,3]; every consumer of the image evaluates the reference's inference
+// transform (ToTensor + Normalize, cell_detection.py:214-227) on the fly: (u8 / 255 - mean[c]) / std[c] in fp32.
+struct InputU8 { const uint8_t* x; float mean[3]; float stdv[3]; };
+// u8 == nullptr: x is the normalised fp32 NCHW batch; otherwise x is ignored and the tile is read through *u8.
+template <typename T> int launch_patchify(const float* x, const InputU8* u8, void* out, int B, int H, int W, hipStream_t stream);
 
 // x fp32 NCHW [B,3,H,W] -> NHWC [B,H,W,8] of T, channels 3..7 zero (decoder0 input, cellvit.py:182,241).
-template <typename T> int launch_nchw3_to_nhwc8(const float* x, void* out, int B, int H, int W, int CP, hipStream_t stream);
+template <typename T> int launch_nchw3_to_nhwc8(const float* x, const InputU8* u8, void* out, int B, int H, int W, int CP, hipStream_t stream);
+
+// argmax over the channels of an fp32 NCHW map -> u8 [B, H*W] (first maximum, as torch.argmax; cellvit.py:366-374)
+int launch_argmax_nchw(const float* x, uint8_t* out, int B, int C, long hw, hipStream_t stream);
+// u8 NHWC -> normalised fp32 NCHW [B,3,H*W] (the tensor the reference's DataLoader hands to model.forward)
+int launch_normalize_u8(const InputU8& u8, float* out, int B, long hw, hipStream_t stream);
+// cell-token pooling (cell_detection.py:396-409): out[rec_off[b] + slot, :] = mean of tokens_nhwc[b, r0:r1, c0:c1, :] for
+// record slot < n_recs[b] of tile b (records: stride rec_stride bytes, leading int32 id, rmin, cmin, rmax, cmax)
+int launch_pool_tokens(const float* tokens_nhwc, const void* recs, int rec_stride, int max_inst, const int32_t* n_recs,
+                       const int64_t* rec_off, int B, int max_n, int gh, int gw, int D, int patch, float* out, hipStream_t stream);
 
 // fp32 token rows -> T rows, optionally dropping a leading cls row per image (cellvit.py:186-189).
 // in: [B, rpi_in, C] (rpi_in = ntok incl. cls); out: [B, ntok_out, C] with ntok_out = rpi_in - skip.

@@ -127,9 +127,16 @@ __global__ __launch_bounds__(256, MAXV <= 5 ? 8 : 4) void layernorm_add_kernel(f
     }
 }
 
-template <typename T>
-__global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int H, int W) {
-    // one thread = 4 consecutive kx of one (token, c, ky): 16-B fp32 read, 4 elements written
+// Inference transform of the reference CLI (T.ToTensor + T.Normalize, cell_detection.py:214-227) evaluated on the fly
+// when the input is the raw uint8 HWC tile: v = (u8 / 255 - mean[c]) / std[c], fp32, the same three roundings as torch
+// (true division, -ffp-contract=off).
+struct U8Norm { float mean[3]; float stdv[3]; };
+__device__ __forceinline__ float u8_norm(uint8_t v, float mean, float stdv) { return ((float)v / 255.0f - mean) / stdv; }
+
+template <typename T, bool U8>
+__global__ void patchify_kernel(const float* __restrict__ x, const uint8_t* __restrict__ x8, U8Norm nm, T* __restrict__ out,
+                                int B, int H, int W) {
+    // one thread = 4 consecutive kx of one (token, c, ky): 16-B fp32 read (or 4 bytes at stride 3), 4 elements written
     const int gw = W >> 4, gh = H >> 4;
     const long total = (long)B * gh * gw * 192;   // 768 / 4
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -140,7 +147,15 @@ __global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ out
         const int b = (int)(tok / (gh * gw));
         const int t = (int)(tok - (long)b * gh * gw);
         const int ty = t / gw, tx = t - ty * gw;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)b * 3 + c) * H + ty * 16 + ky) * W + tx * 16 + kx);
+        f32x4 v;
+        if constexpr (U8) {
+            const uint8_t* s8 = x8 + (((long)b * H + ty * 16 + ky) * W + tx * 16 + kx) * 3 + c;
+            const float mu = nm.mean[c], sd = nm.stdv[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = u8_norm(s8[j * 3], mu, sd);
+        } else {
+            v = *reinterpret_cast<const f32x4*>(x + (((long)b * 3 + c) * H + ty * 16 + ky) * W + tx * 16 + kx);
+        }
         T* o = out + tok * 768 + k;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = Traits<T>::from_float(v[j]);
@@ -149,8 +164,9 @@ __global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ out
 
 // NCHW fp32 image (3 channels) -> NHWC of T with the channel count padded to CP (8: implicit-GEMM path, 32: the halo
 // convolution kernel, which wants whole 32-channel chunks); one thread per (pixel, 8-channel group)
-template <typename T>
-__global__ void nhwc8_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int H, int W, int CP) {
+template <typename T, bool U8>
+__global__ void nhwc8_kernel(const float* __restrict__ x, const uint8_t* __restrict__ x8, U8Norm nm, T* __restrict__ out, int B,
+                             int H, int W, int CP) {
     const long hw = (long)H * W;
     const int groups = CP >> 3;
     const long total = (long)B * hw * groups;
@@ -163,7 +179,8 @@ __global__ void nhwc8_kernel(const float* __restrict__ x, T* __restrict__ out, i
         for (int c = 0; c < 8; ++c) v[c] = Traits<T>::from_float(0.f);
         if (gq == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] = Traits<T>::from_float(x[(b * 3 + c) * hw + r]);
+            for (int c = 0; c < 3; ++c)
+                v[c] = Traits<T>::from_float(U8 ? u8_norm(x8[pix * 3 + c], nm.mean[c], nm.stdv[c]) : x[(b * 3 + c) * hw + r]);
         }
         T* o = out + pix * CP + gq * 8;
 #pragma unroll
@@ -264,6 +281,52 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const T* __restrict__ feat
     }
 }
 
+// argmax over the channel dim of an NCHW fp32 map (first maximum, as torch.argmax): the nuclei_binary_map /
+// nuclei_type_map reduction of calculate_instance_map (cellvit.py:366-374) for maps that did not come with argmax planes
+__global__ void argmax_nchw_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int C, long hw, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / hw, r = i - b * hw;
+        const float* p = x + b * C * hw + r;
+        float bv = p[0]; int best = 0;
+        for (int c = 1; c < C; ++c) { const float v = p[c * hw]; if (v > bv) { bv = v; best = c; } }
+        out[i] = (uint8_t)best;
+    }
+}
+
+// u8 HWC -> normalised fp32 NCHW (what the reference hands to model.forward); parity helper for the fused input path
+__global__ void normalize_u8_kernel(const uint8_t* __restrict__ x8, U8Norm nm, float* __restrict__ out, long hw, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / hw, r = i - b * hw;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(b * 3 + c) * hw + r] = u8_norm(x8[i * 3 + c], nm.mean[c], nm.stdv[c]);
+    }
+}
+
+// Cell-token pooling (cell_detection.py:396-409): per instance record, mean of the encoder tokens under the bbox / patch
+// window [floor(rmin/p), ceil(rmax/p)) x [floor(cmin/p), ceil(cmax/p)), indices cast to uint8 as the reference does.
+// One workgroup per record; rows of the window are summed in raster order (the reference's (H W) order), then / count.
+struct PoolRec { int32_t id, rmin, cmin, rmax, cmax; };
+__global__ __launch_bounds__(256) void pool_tokens_kernel(const float* __restrict__ tok, const unsigned char* __restrict__ recs,
+                                                          int rec_stride, int max_inst, const int32_t* __restrict__ n_recs,
+                                                          const int64_t* __restrict__ rec_off, int gh, int gw, int D, int patch,
+                                                          float* __restrict__ out) {
+    const int b = blockIdx.y, slot = blockIdx.x;
+    if (slot >= n_recs[b] || slot >= max_inst) return;
+    const PoolRec r = *reinterpret_cast<const PoolRec*>(recs + ((long)b * max_inst + slot) * rec_stride);
+    const int r0 = (r.rmin / patch) & 255, c0 = (r.cmin / patch) & 255;                       // floor (bbox >= 0), uint8 cast
+    const int r1 = ((r.rmax + patch - 1) / patch) & 255, c1 = ((r.cmax + patch - 1) / patch) & 255;   // ceil
+    const int rr1 = r1 < gh ? r1 : gh, cc1 = c1 < gw ? c1 : gw;                                 // python slicing clamps
+    const int cnt = (rr1 > r0 ? rr1 - r0 : 0) * (cc1 > c0 ? cc1 - c0 : 0);
+    float* o = out + (rec_off[b] + slot) * D;
+    const float* base = tok + (long)b * gh * gw * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float s = 0.f;
+        for (int y = r0; y < rr1; ++y)
+            for (int x = c0; x < cc1; ++x) s += base[((long)y * gw + x) * D + d];
+        o[d] = cnt > 0 ? s / (float)cnt : __builtin_nanf("");                              // torch.mean of an empty slice is nan
+    }
+}
+
 inline int grid_for(long total, int per_block = 256, int cap = 16384) {
     long g = (total + per_block - 1) / per_block;
     return (int)(g > cap ? cap : (g < 1 ? 1 : g));
@@ -279,7 +342,7 @@ int launch_layernorm(const float* in, long ld_in, const float* gamma, const floa
     if (C <= 64 * 4 * 2)
         hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
     else if (C <= 64 * 4 * 5) {
-        static const int nt = [] { const char* e = getenv("CVA_LN"); return e ? atoi(e) : 1; }();   // 1 (default): nontemporal loads / stores
+        static const int nt = cva_env_int("CVA_LN", 1);   // 1 (default): nontemporal loads / stores
         if (nt == 2) hipLaunchKernelGGL((layernorm_kernel<T, 5, 2>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
         else if (nt == 1) hipLaunchKernelGGL((layernorm_kernel<T, 5, 1>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
         else hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, stream, in, ld_in, gamma, beta, out, out_f32, M, C, eps);
@@ -301,19 +364,51 @@ int launch_layernorm_add(float* x_io, long ld, const void* delta, const float* g
     return (int)hipGetLastError();
 }
 
+static U8Norm make_norm(const InputU8* u8) {
+    U8Norm nm{};
+    if (u8) for (int c = 0; c < 3; ++c) { nm.mean[c] = u8->mean[c]; nm.stdv[c] = u8->stdv[c]; }
+    return nm;
+}
+
 template <typename T>
-int launch_patchify(const float* x, void* out, int B, int H, int W, hipStream_t stream) {
+int launch_patchify(const float* x, const InputU8* u8, void* out, int B, int H, int W, hipStream_t stream) {
     const long total = (long)B * (H / 16) * (W / 16) * 192;
-    hipLaunchKernelGGL((patchify_kernel<T>), dim3(grid_for(total)), dim3(256), 0, stream, x,
-                       reinterpret_cast<T*>(out), B, H, W);
+    const U8Norm nm = make_norm(u8);
+    if (u8) hipLaunchKernelGGL((patchify_kernel<T, true>), dim3(grid_for(total)), dim3(256), 0, stream, nullptr, u8->x, nm,
+                               reinterpret_cast<T*>(out), B, H, W);
+    else hipLaunchKernelGGL((patchify_kernel<T, false>), dim3(grid_for(total)), dim3(256), 0, stream, x, nullptr, nm,
+                            reinterpret_cast<T*>(out), B, H, W);
     return (int)hipGetLastError();
 }
 
 template <typename T>
-int launch_nchw3_to_nhwc8(const float* x, void* out, int B, int H, int W, int CP, hipStream_t stream) {
+int launch_nchw3_to_nhwc8(const float* x, const InputU8* u8, void* out, int B, int H, int W, int CP, hipStream_t stream) {
     if (CP < 8 || (CP & 7)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((nhwc8_kernel<T>), dim3(grid_for((long)B * H * W * (CP >> 3))), dim3(256), 0, stream, x,
-                       reinterpret_cast<T*>(out), B, H, W, CP);
+    const U8Norm nm = make_norm(u8);
+    const dim3 grid(grid_for((long)B * H * W * (CP >> 3)));
+    if (u8) hipLaunchKernelGGL((nhwc8_kernel<T, true>), grid, dim3(256), 0, stream, nullptr, u8->x, nm, reinterpret_cast<T*>(out), B, H, W, CP);
+    else hipLaunchKernelGGL((nhwc8_kernel<T, false>), grid, dim3(256), 0, stream, x, nullptr, nm, reinterpret_cast<T*>(out), B, H, W, CP);
+    return (int)hipGetLastError();
+}
+
+int launch_argmax_nchw(const float* x, uint8_t* out, int B, int C, long hw, hipStream_t stream) {
+    if (C < 1 || C > 255) return (int)hipErrorInvalidValue;
+    const long total = (long)B * hw;
+    hipLaunchKernelGGL(argmax_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, out, C, hw, total);
+    return (int)hipGetLastError();
+}
+
+int launch_normalize_u8(const InputU8& u8, float* out, int B, long hw, hipStream_t stream) {
+    const long total = (long)B * hw;
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3(grid_for(total)), dim3(256), 0, stream, u8.x, make_norm(&u8), out, hw, total);
+    return (int)hipGetLastError();
+}
+
+int launch_pool_tokens(const float* tokens_nhwc, const void* recs, int rec_stride, int max_inst, const int32_t* n_recs,
+                       const int64_t* rec_off, int B, int max_n, int gh, int gw, int D, int patch, float* out, hipStream_t stream) {
+    if (max_n <= 0 || B <= 0) return 0;
+    hipLaunchKernelGGL(pool_tokens_kernel, dim3(max_n, B), dim3(256), 0, stream, tokens_nhwc,
+                       reinterpret_cast<const unsigned char*>(recs), rec_stride, max_inst, n_recs, rec_off, gh, gw, D, patch, out);
     return (int)hipGetLastError();
 }
 
@@ -360,8 +455,8 @@ int launch_head1x1(const void* feat, const float* Wt, const float* bias, float* 
 #define CVA_INST(T)                                                                                               \
     template int launch_layernorm<T>(const float*, long, const float*, const float*, void*, int, int, int, float, \
                                      hipStream_t);                                                                \
-    template int launch_patchify<T>(const float*, void*, int, int, int, hipStream_t);                             \
-    template int launch_nchw3_to_nhwc8<T>(const float*, void*, int, int, int, int, hipStream_t);                       \
+    template int launch_patchify<T>(const float*, const InputU8*, void*, int, int, int, hipStream_t);            \
+    template int launch_nchw3_to_nhwc8<T>(const float*, const InputU8*, void*, int, int, int, int, hipStream_t); \
     template int launch_cast_tokens<T>(const float*, void*, int, int, int, int, hipStream_t);                     \
     template int launch_cast<T>(const float*, void*, long, hipStream_t);                                          \
     template int launch_head1x1<T>(const void*, const float*, const float*, float*, uint8_t*, int, long, int, int, \

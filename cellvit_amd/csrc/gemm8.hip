@@ -586,6 +586,7 @@ bool gemm8_supported(const GemmParams& p, int a_mode, size_t elem_size) {
 
 int launch_gemm8(const GemmParams& p, hipStream_t stream) {
     if (p.out_mode == OUT_LINEAR) {
+#ifdef CVA_ABLATION      // work-skipping instantiations exist in ablation builds only (p.dbg is 0 otherwise)
         switch (p.dbg & 7) {
             case 4: return launch8<OUT_LINEAR, 1, 4>(p, stream);
             case 7: return launch8<OUT_LINEAR, 1, 7>(p, stream);
@@ -593,8 +594,10 @@ int launch_gemm8(const GemmParams& p, hipStream_t stream) {
             case 2: return launch8<OUT_LINEAR, 1, 2>(p, stream);
             case 3: return launch8<OUT_LINEAR, 1, 3>(p, stream);
             case 5: return launch8<OUT_LINEAR, 0, 0>(p, stream);      // LDS-staged epilogue, for A/B
-            default: return launch8<OUT_LINEAR, 1, 0>(p, stream);
+            default: break;
         }
+#endif
+        return launch8<OUT_LINEAR, 1, 0>(p, stream);
     }
     if (p.out_mode == OUT_QKV) return launch8<OUT_QKV, 1, 0>(p, stream);
     if ((p.N >> 2) % 16 == 0 && !p.out_f32 && !(p.dbg & 2048)) return launch8<OUT_CONVT, 1, 0>(p, stream);   // direct 32-byte runs

@@ -11,6 +11,7 @@
 // Floating point: this file must be compiled with -ffp-contract=off; the only fused operations are
 // the explicit fmaf()/fma() that restate OpenCV's convertTo (see oracle/postproc_ref.c).
 #include "postproc.h"
+#include "common.h"
 
 #include <float.h>
 
@@ -97,10 +98,36 @@ __global__ void k_cc_merge_runs(int* __restrict__ Lb, int H, int W) {
     }
 }
 
-__global__ void k_cc_flatten(int* __restrict__ Lb, int N) {
-    int* L = Lb + (long)blockIdx.y * N;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
-        if (L[i] >= 0) L[i] = uf_find(L, i);
+// Flatten the forest; roots (L[i] == i: stable during this pass) also initialise the per-component accumulators of the
+// kernels that follow — only root slots of those planes are ever read, so no whole-plane hipMemset is needed:
+//   INIT 1: csize[root] = 0, bb planes (y0, y1, x0, x1)[root] = (+big, -1, +big, -1)   (k_comp_stats)
+//   INIT 2: flag[root] = 0                                                            (k_border_flag / k_fill)
+template <int INIT>
+__global__ void k_cc_flatten(int* __restrict__ Lb, int N, int* __restrict__ csize, int* __restrict__ bb, int* __restrict__ flag) {
+    const long base = (long)blockIdx.y * N;
+    int* L = Lb + base;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int v = L[i];
+        if (v < 0) continue;
+        if (v == i) {
+            if (INIT == 1) {
+                csize[base + i] = 0;
+                int* y0 = bb + base * 4;
+                y0[i] = 0x7f7f7f7f; y0[(long)N + i] = -1; y0[2l * N + i] = 0x7f7f7f7f; y0[3l * N + i] = -1;
+            } else if (INIT == 2) {
+                flag[base + i] = 0;
+            }
+        } else {
+            L[i] = uf_find(L, i);
+        }
+    }
+}
+
+// zero the few per-tile scalars of a run (component counter, flood queue head, marker count, overflow cursor)
+__global__ void k_init_small(int* __restrict__ counters, unsigned long long* __restrict__ ovf_cursor, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 * B) counters[i] = 0;
+    if (i < B) ovf_cursor[i] = 0ull;
 }
 
 // ---- P1: component sizes / bounding boxes of the raw binary mask ----
@@ -651,6 +678,23 @@ struct StatArrays {       // all [B][max_ids + 1] unless noted
     int* rmin; int* rmax; int* cmin; int* cmax; int* first; unsigned* hist /* [..][8] */; int* has_zero /* [B] */;
 };
 
+// Reset the per-id accumulators of the ids a tile can actually use (1 .. nmark[tile], the number of marker components)
+// instead of memsetting all max_ids + 1 slots of eleven arrays: ~10^3 ids per tile against 65537 slots.
+__global__ void k_stats_init(StatArrays st, int* __restrict__ msize, const int* __restrict__ nmark, int max_ids) {
+    const int tile = blockIdx.y;
+    const long sb = (long)tile * (max_ids + 1);
+    const int hi = min(max_ids, nmark[tile]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.has_zero[tile] = 0;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id <= hi; id += gridDim.x * blockDim.x) {
+        msize[sb + id] = 0;
+        st.cnt[sb + id] = 0; st.sx[sb + id] = 0ull; st.sy[sb + id] = 0ull;
+        st.rmin[sb + id] = 0x7f7f7f7f; st.cmin[sb + id] = 0x7f7f7f7f; st.first[sb + id] = 0x7f7f7f7f;
+        st.rmax[sb + id] = -1; st.cmax[sb + id] = -1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st.hist[(sb + id) * 8 + k] = 0u;
+    }
+}
+
 __global__ void k_inst_stats(int* __restrict__ inst, const uint8_t* __restrict__ type, StatArrays st, int H, int W,
                              int max_ids, int nr_types) {
     const int N = H * W, tile = blockIdx.y;
@@ -734,7 +778,7 @@ __global__ void k_inst_records(StatArrays st, InstanceRec* __restrict__ recs, in
     }
     if (threadIdx.x == 0) {
         int n = s_base - (drop_first && s_base > 0 ? 1 : 0);
-        n_recs[tile] = n > max_inst ? max_inst : n;
+        n_recs[tile] = n;      // the TRUE count: n > max_inst tells the caller that records were dropped (capacity overflow)
     }
 }
 
@@ -762,7 +806,8 @@ __device__ int trace_contour(const int* __restrict__ inst, int H, int W, int id,
 __global__ void k_contour_count(const int* __restrict__ inst, InstanceRec* __restrict__ recs, const int* __restrict__ n_recs,
                                 int H, int W, int max_inst) {
     const int tile = blockIdx.y, N = H * W;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_recs[tile]; k += gridDim.x * blockDim.x) {
+    const int nr = min(n_recs[tile], max_inst);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nr; k += gridDim.x * blockDim.x) {
         InstanceRec* r = &recs[(long)tile * max_inst + k];
         const int f = r->contour_off;
         r->contour_len = trace_contour(inst + (long)tile * N, H, W, r->id, f % W, f / W, nullptr);
@@ -773,7 +818,7 @@ __global__ void k_contour_count(const int* __restrict__ inst, InstanceRec* __res
 __global__ void k_contour_offsets(InstanceRec* __restrict__ recs, const int* __restrict__ n_recs, int* __restrict__ n_pts,
                                   int max_inst) {
     const int tile = blockIdx.x;
-    const int n = n_recs[tile];
+    const int n = min(n_recs[tile], max_inst);
     __shared__ int s_base;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
@@ -794,7 +839,8 @@ __global__ void k_contour_offsets(InstanceRec* __restrict__ recs, const int* __r
 __global__ void k_contour_write(const int* __restrict__ inst, InstanceRec* __restrict__ recs, const int* __restrict__ n_recs,
                                 int* __restrict__ contours, int H, int W, int max_inst, int max_pts) {
     const int tile = blockIdx.y, N = H * W;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_recs[tile]; k += gridDim.x * blockDim.x) {
+    const int nr = min(n_recs[tile], max_inst);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nr; k += gridDim.x * blockDim.x) {
         InstanceRec* r = &recs[(long)tile * max_inst + k];
         const int f = r->_pad;
         r->_pad = 0;
@@ -894,15 +940,12 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     const dim3 grid(gx, B), blk(NT);
     SobelTaps taps;
     sobel_taps(ksize, &taps);
-    const size_t S = (size_t)B * (d.max_ids + 1);
-#define CVA_MS(ptr, val, bytes) if (hipMemsetAsync(ptr, val, bytes, st) != hipSuccess) return 2
+    // No hipMemset anywhere in this chain: accumulator planes are initialised at the component roots by the flatten pass
+    // that precedes their first use (k_cc_flatten<INIT>), per-id arrays for the live ids only (k_stats_init).
     // ---- P1: mask, 4-connected components, small-object removal (hard-wired 10) ----
-    CVA_MS(w->csize, 0, (size_t)B * N * 4);
-    CVA_MS(w->bb, 0x7f, (size_t)B * N * 16);            // y0 / x0 = large positive for atomicMin
-    CVA_MS(w->counters, 0, (size_t)B * 16);
-    CVA_MS(w->ovf_cursor, 0, (size_t)B * 8);
+    hipLaunchKernelGGL(k_init_small, dim3((4 * B + NT - 1) / NT), blk, 0, st, w->counters, w->ovf_cursor, B);
     const bool runs = (W % 64) == 0;
-    auto cc = [&](const uint8_t* src, int invert, int* L) {
+    auto cc = [&](const uint8_t* src, int invert, int* L, int init) {
         if (runs) {
             hipLaunchKernelGGL(k_cc_init_runs, grid, blk, 0, st, src, invert, L, N);
             hipLaunchKernelGGL(k_cc_merge_runs, grid, blk, 0, st, L, H, W);
@@ -910,12 +953,11 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
             hipLaunchKernelGGL(k_cc_init, grid, blk, 0, st, src, invert, L, N);
             hipLaunchKernelGGL(k_cc_merge, grid, blk, 0, st, L, H, W);
         }
-        hipLaunchKernelGGL(k_cc_flatten, grid, blk, 0, st, L, N);
+        if (init == 1) hipLaunchKernelGGL(k_cc_flatten<1>, grid, blk, 0, st, L, N, w->csize, w->bb, w->flag);
+        else if (init == 2) hipLaunchKernelGGL(k_cc_flatten<2>, grid, blk, 0, st, L, N, w->csize, w->bb, w->flag);
+        else hipLaunchKernelGGL(k_cc_flatten<0>, grid, blk, 0, st, L, N, w->csize, w->bb, w->flag);
     };
-    cc(bin, 0, w->L1);
-    // y1 / x1 planes must start at -1 for atomicMax: overwrite those two planes
-    for (int b = 0; b < B; ++b) CVA_MS(w->bb + ((size_t)b * 4 + 1) * N, 0xff, (size_t)N * 4);
-    for (int b = 0; b < B; ++b) CVA_MS(w->bb + ((size_t)b * 4 + 3) * N, 0xff, (size_t)N * 4);
+    cc(bin, 0, w->L1, 1);
     hipLaunchKernelGGL(k_comp_stats, grid, blk, 0, st, w->L1, w->csize, w->bb, H, W);
     int* comp_count = w->counters;            // [B]
     int* queue_head = w->counters + B;        // [B]
@@ -931,18 +973,17 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     hipLaunchKernelGGL(k_combine, grid, blk, 0, st, w->sob, w->params_sob, w->blb, w->d0, w->mk, N);
     hipLaunchKernelGGL(k_blur_neg, grid, blk, 0, st, w->d0, w->dist, H, W);
     // ---- P5: fill holes (background components not touching the border), open, label, size filter ----
-    cc(w->mk, 1, w->L2);
-    CVA_MS(w->flag, 0, (size_t)B * N * 4);
+    cc(w->mk, 1, w->L2, 2);
     hipLaunchKernelGGL(k_border_flag, dim3((2 * (H + W) + NT - 1) / NT, B), blk, 0, st, w->L2, w->flag, H, W);
     hipLaunchKernelGGL(k_fill, grid, blk, 0, st, w->mk, w->L2, w->flag, w->mk2, N);
     hipLaunchKernelGGL((k_morph5<true>), grid, blk, 0, st, w->mk2, w->mk, H, W);
     hipLaunchKernelGGL((k_morph5<false>), grid, blk, 0, st, w->mk, w->mk2, H, W);
-    cc(w->mk2, 0, w->L2);
+    cc(w->mk2, 0, w->L2, 0);
     hipLaunchKernelGGL(k_scan_partial, dim3(w->nblk, B), blk, 0, st, w->L2, N, w->bsum, w->nblk);
     int* nmark = w->counters + 2 * B;         // [B]
     hipLaunchKernelGGL(k_scan_blocks, dim3(B), blk, 0, st, w->bsum, w->nblk, nmark);
     hipLaunchKernelGGL(k_scan_apply, dim3(w->nblk, B), blk, 0, st, w->L2, N, w->bsum, w->nblk, w->rank);
-    CVA_MS(w->msize, 0, S * 4);
+    hipLaunchKernelGGL(k_stats_init, dim3(std::min((d.max_ids + NT) / NT, 32), B), blk, 0, st, w->st, w->msize, nmark, d.max_ids);
     hipLaunchKernelGGL(k_marker_ids, grid, blk, 0, st, w->L2, w->rank, w->marker, w->msize, N, W, d.max_ids);
     hipLaunchKernelGGL(k_marker_filter, grid, blk, 0, st, w->marker, w->msize, object_size, w->blb, inst_out, N, d.max_ids);
     // ---- P6: ordered flood ----
@@ -951,13 +992,9 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     fp.comp_list = w->comp_list; fp.comp_count = comp_count; fp.list_cap = w->list_cap; fp.queue_head = queue_head;
     fp.ovf_hi = reinterpret_cast<unsigned long long*>(w->ovf_v); fp.ovf_lo = w->ovf_lo; fp.ovf_lab = w->ovf_lab; fp.ovf_cursor = w->ovf_cursor;
     fp.H = H; fp.W = W; fp.B = B;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CVA_PP_DBG"); dbg = e ? atoi(e) : 0; } fp.dbg = dbg; }
+    { static const int dbg = cva_env_int("CVA_PP_DBG", 0); fp.dbg = dbg; }   // ablation builds only (common.h)
     hipLaunchKernelGGL(k_flood, dim3(1024, B), dim3(64), 0, st, fp);
     // ---- P7/P8: per-instance records + contours ----
-    CVA_MS(w->st.cnt, 0, S * 4); CVA_MS(w->st.sx, 0, S * 8); CVA_MS(w->st.sy, 0, S * 8);
-    CVA_MS(w->st.rmin, 0x7f, S * 4); CVA_MS(w->st.cmin, 0x7f, S * 4); CVA_MS(w->st.first, 0x7f, S * 4);
-    CVA_MS(w->st.rmax, 0xff, S * 4); CVA_MS(w->st.cmax, 0xff, S * 4);
-    CVA_MS(w->st.hist, 0, S * 32); CVA_MS(w->st.has_zero, 0, (size_t)B * 4);
     hipLaunchKernelGGL(k_inst_stats, grid, blk, 0, st, inst_out, type, w->st, H, W, d.max_ids, nr_types);
     hipLaunchKernelGGL(k_inst_records, dim3(B), blk, 0, st, w->st, recs, n_recs, d.max_ids, d.max_inst, nr_types, nmark);
     const dim3 cgrid((d.max_inst + 63) / 64 > 64 ? 64 : (d.max_inst + 63) / 64, B);
@@ -965,7 +1002,6 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     hipLaunchKernelGGL(k_contour_offsets, dim3(B), blk, 0, st, recs, n_recs, n_pts, d.max_inst);
     if (contours)
         hipLaunchKernelGGL(k_contour_write, cgrid, dim3(64), 0, st, inst_out, recs, n_recs, contours, H, W, d.max_inst, d.max_pts);
-#undef CVA_MS
     return (int)hipGetLastError();
 }
 

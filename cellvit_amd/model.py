@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 from collections import OrderedDict
 from pathlib import Path
 from typing import Dict, List, Literal, Optional, Tuple, Union
@@ -173,6 +174,10 @@ class CellViT(nn.Module):
                                  extract_layers=tuple(extract_layers), num_nuclei_classes=num_nuclei_classes,
                                  num_tissue_classes=num_tissue_classes, mlp_ratio=int(mlp_ratio),
                                  regression_loss=regression_loss, pos_grid=14, name="CellViT")
+        if num_tissue_classes <= 0:
+            # reference: the tissue head degenerates to nn.Identity and `tissue_types` becomes the pooled embedding
+            # (vits_histo.py:339, cellvit.py:568-572) — not built here; fail loudly instead of returning garbage
+            raise NotImplementedError("cellvit_amd builds the tissue classification head: num_tissue_classes must be > 0")
         self.cfg = _cfg
         self.patch_size = 16
         self.num_tissue_classes = num_tissue_classes
@@ -192,7 +197,9 @@ class CellViT(nn.Module):
         self.compute_dtype = compute_dtype
         self.debug_taps = False
         _build_tree(self, _cfg)
-        self._engines: Dict[int, _Engine] = {}
+        self._engines: Dict[Tuple[int, int], _Engine] = {}     # (device index, compute dtype) -> packed weights + workspace
+        self._last_argmax = None
+        self._last_maps = None
         self.eval()
 
     # ------------------------------------------------------------------ weights
@@ -227,11 +234,13 @@ class CellViT(nn.Module):
             return _lib.DTYPE_F32
         raise ValueError(f"unknown compute_dtype {cd!r}")
 
-    def _engine(self, dtype: int) -> _Engine:
-        e = self._engines.get(dtype)
+    def _engine(self, dtype: int, device: torch.device) -> _Engine:
+        """One handle per (device, dtype): weights and workspace live on the device that was current at creation."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        e = self._engines.get((idx, dtype))
         if e is None:
             e = _Engine(self.cfg, dtype, self.state_dict(), self.debug_taps)
-            self._engines[dtype] = e
+            self._engines[(idx, dtype)] = e
         return e
 
     def _ensure_geometry(self, e: _Engine, B: int, H: int, W: int) -> None:
@@ -274,15 +283,33 @@ class CellViT(nn.Module):
             raise RuntimeError("cellvit_amd runs on the MI355X only: move the batch to a cuda device "
                                "(there is no CPU fallback; the CPU oracle lives under oracle/ for tests)")
         B, _, H, W = x.shape
+        return self._run(x.contiguous().float(), None, B, H, W, retrieve_tokens)
+
+    @torch.no_grad()
+    def forward_u8(self, tiles_u8: torch.Tensor, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
+                   retrieve_tokens: bool = False) -> dict:
+        """forward() on RAW tiles: uint8 [B, H, W, 3] on the device.  The inference transform of the reference CLI
+        (T.ToTensor + T.Normalize(mean, std), cell_detection.py:214-227) is evaluated inside the kernels that read the
+        image, so `forward_u8(t) == forward(((t / 255 - mean) / std).permute(0, 3, 1, 2))` bit for bit."""
+        if tiles_u8.dim() != 4 or tiles_u8.shape[-1] != 3 or tiles_u8.dtype != torch.uint8:
+            raise ValueError("expected a uint8 batch [B, H, W, 3]")
+        assert tiles_u8.shape[1] % self.patch_size == 0 and tiles_u8.shape[2] % self.patch_size == 0, \
+            "Img must have a shape of that is divisible by patch_size (token_size)"
+        if not tiles_u8.is_cuda:
+            raise RuntimeError("cellvit_amd runs on the MI355X only: move the batch to a cuda device")
+        B, H, W, _ = tiles_u8.shape
+        nm = ((C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std]))
+        return self._run(tiles_u8.contiguous(), nm, B, H, W, retrieve_tokens)
+
+    def _run(self, x: torch.Tensor, u8_norm, B: int, H: int, W: int, retrieve_tokens: bool) -> dict:
         with torch.cuda.device(x.device):
-            e = self._engine(self._dtype_code())
+            e = self._engine(self._dtype_code(), x.device)
             self._ensure_geometry(e, B, H, W)
-            x = x.contiguous().float()
             cfg = self.cfg
             dev = x.device
             f32 = dict(device=dev, dtype=torch.float32)
             out_t = {
-                "tissue_types": torch.empty((B, max(cfg.num_tissue_classes, 1)), **f32),
+                "tissue_types": torch.empty((B, cfg.num_tissue_classes), **f32),
                 "nuclei_binary_map": torch.empty((B, 2, H, W), **f32),
                 "hv_map": torch.empty((B, 2, H, W), **f32),
                 "nuclei_type_map": torch.empty((B, cfg.num_nuclei_classes, H, W), **f32),
@@ -293,7 +320,7 @@ class CellViT(nn.Module):
             bin_am = torch.empty((B, H, W), device=dev, dtype=torch.uint8)
             typ_am = torch.empty((B, H, W), device=dev, dtype=torch.uint8)
             o = _lib.cv_outputs()
-            o.tissue_types = out_t["tissue_types"].data_ptr() if cfg.num_tissue_classes > 0 else None
+            o.tissue_types = out_t["tissue_types"].data_ptr()
             o.nuclei_binary_map = out_t["nuclei_binary_map"].data_ptr()
             o.hv_map = out_t["hv_map"].data_ptr()
             o.nuclei_type_map = out_t["nuclei_type_map"].data_ptr()
@@ -301,8 +328,11 @@ class CellViT(nn.Module):
             o.tokens_nhwc = tokens.data_ptr() if tokens is not None else None
             o.binary_argmax = bin_am.data_ptr()
             o.type_argmax = typ_am.data_ptr()
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(e.lib.cv_forward(e.h, x.data_ptr(), B, H, W, C.byref(o), C.c_void_p(stream)))
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            if u8_norm is None:
+                _lib.check(e.lib.cv_forward(e.h, x.data_ptr(), B, H, W, C.byref(o), stream))
+            else:
+                _lib.check(e.lib.cv_forward_u8(e.h, x.data_ptr(), u8_norm[0], u8_norm[1], B, H, W, C.byref(o), stream))
         out_dict = {"tissue_types": out_t["tissue_types"]}
         out_dict["nuclei_binary_map"] = out_t["nuclei_binary_map"]
         if cfg.regression_loss:
@@ -311,7 +341,10 @@ class CellViT(nn.Module):
         out_dict["nuclei_type_map"] = out_t["nuclei_type_map"]
         if retrieve_tokens:
             out_dict["tokens"] = tokens.permute(0, 3, 1, 2)
+        # u8 argmax planes of the two classification maps, written by the kernels that produce the logits; valid for
+        # calculate_instance_map as long as the caller hands back these very tensors, unmodified (see there)
         self._last_argmax = (bin_am, typ_am)
+        self._last_maps = tuple((weakref.ref(t), t._version) for t in (out_t["nuclei_binary_map"], out_t["nuclei_type_map"]))
         self._last_engine = e
         return out_dict
 
@@ -326,19 +359,43 @@ class CellViT(nn.Module):
     # ------------------------------------------------------------------ post-processing
     def calculate_instance_map(self, predictions: OrderedDict, magnification: Literal[20, 40] = 40
                                ) -> Tuple[torch.Tensor, List[dict]]:
-        """cellvit.py:332-383 — instance map [B,H,W] float32 + per-image dict of nuclei."""
+        """cellvit.py:332-383 — instance map [B,H,W] float32 + per-image dict of nuclei.
+
+        The reference takes torch.argmax of the two classification maps (:366-374).  When `predictions` still holds
+        the tensors the last forward() returned, untouched (same objects, same in-place version), the u8 argmax planes
+        the forward kernels wrote next to the logits are used; for any other maps (e.g. after the CLI's softmax,
+        cell_detection.py:500-505) the channel argmax runs as a HIP kernel on the maps given."""
         from .postproc import calculate_instance_map as _cim
-        return _cim(predictions, self.num_nuclei_classes, magnification)
+        planes = None
+        if self._last_maps is not None and self._last_argmax is not None:
+            (rb, vb), (rt, vt) = self._last_maps
+            tb, tt = rb(), rt()
+            if tb is not None and tt is not None and predictions.get("nuclei_binary_map") is tb \
+                    and predictions.get("nuclei_type_map") is tt and tb._version == vb and tt._version == vt:
+                planes = self._last_argmax
+        return _cim(predictions, self.num_nuclei_classes, magnification, argmax_planes=planes)
 
     def generate_instance_nuclei_map(self, instance_maps: torch.Tensor, type_preds: List[dict]) -> torch.Tensor:
-        """cellvit.py:385-414 — [B,H,W] ids + dicts -> [B, num_nuclei_classes, H, W] per-class id maps."""
+        """cellvit.py:385-414 — [B,H,W] ids + dicts -> [B, num_nuclei_classes, H, W] per-class id maps (float32, on
+        the host like the reference).  Instances that are not in the dict (quirk 4: failed the contour test,
+        post_proc:113-116) stay unpainted.  One id -> class lookup table per image instead of the reference's
+        per-instance full-image comparisons; runs on whatever device `instance_maps` lives on."""
         batch_size, h, w = instance_maps.shape
-        out = torch.zeros((batch_size, self.num_nuclei_classes, h, w))
-        im = instance_maps.cpu()
+        dev = instance_maps.device
+        out = torch.zeros((batch_size, self.num_nuclei_classes, h, w), dtype=torch.float32, device=dev)
         for i in range(batch_size):
-            for nuclei, spec in type_preds[i].items():
-                out[i, spec["type"]][im[i] == nuclei] = nuclei
-        return out
+            im = instance_maps[i].to(torch.int64)
+            n = int(im.max().item()) + 1 if im.numel() else 1
+            lut = torch.full((max(n, 1),), -1, dtype=torch.int64, device=dev)
+            ids = [int(k) for k in type_preds[i].keys() if 0 <= int(k) < n]
+            if ids:
+                lut[torch.tensor(ids, device=dev)] = torch.tensor([int(type_preds[i][k]["type"]) for k in ids], device=dev)
+            cls = lut[im.clamp(min=0)]                      # class of every pixel's instance, -1 = not painted
+            cls = torch.where(im > 0, cls, torch.full_like(cls, -1)) if 0 not in type_preds[i] else cls
+            valid = cls >= 0
+            out[i].view(self.num_nuclei_classes, -1)[cls[valid], valid.view(-1).nonzero(as_tuple=True)[0]] = \
+                instance_maps[i][valid].to(torch.float32)
+        return out.cpu()
 
 
 class CellViT256(CellViT):

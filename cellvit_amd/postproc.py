@@ -18,14 +18,32 @@ import torch
 from . import _lib
 
 
+# Capacity of the per-tile device arrays, as divisors of the pixel count.  The defaults hold 8192 instance records and
+# 131072 contour points per 1024^2 tile (a dense tile has ~1500 nuclei).  A tile that exceeds them is REPORTED
+# (records_to_dicts raises CapacityError); call set_capacity() with smaller divisors and re-run.
+_CAP = {"inst_div": 128, "pts_div": 8}
+
+
+class CapacityError(RuntimeError):
+    """More instances / contour points in a tile than the post-processing handle has slots for."""
+
+
+def set_capacity(inst_div: int = 128, pts_div: int = 8) -> None:
+    """Record slots per tile = H*W // inst_div, contour points per tile = H*W // pts_div (handles are rebuilt lazily)."""
+    _CAP["inst_div"], _CAP["pts_div"] = int(inst_div), int(pts_div)
+    for e in list(_PPEngine._cache.values()):
+        e.close()
+    _PPEngine._cache.clear()
+
+
 class _PPEngine:
     _cache: Dict[tuple, "_PPEngine"] = {}
 
     def __init__(self, device: torch.device, B: int, H: int, W: int):
         self.lib = _lib.load()
         self.B, self.H, self.W = B, H, W
-        self.max_inst = max(256, H * W // 128)       # record slots per tile (1024^2 -> 8192)
-        self.max_pts = max(4096, H * W // 8)         # contour points per tile
+        self.max_inst = max(256, H * W // _CAP["inst_div"])   # record slots per tile (1024^2 -> 8192)
+        self.max_pts = max(4096, H * W // _CAP["pts_div"])    # contour points per tile
         h = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(self.lib.cv_pp_create(B, H, W, self.max_inst, self.max_pts, C.byref(h)))
@@ -78,20 +96,36 @@ def postprocess_device(bin_argmax: torch.Tensor, type_argmax: Optional[torch.Ten
     return inst, recs, n_recs, contours, n_pts
 
 
+def check_capacity(recs: torch.Tensor, n_recs_host: np.ndarray, contours: Optional[torch.Tensor],
+                   n_pts_host: np.ndarray) -> None:
+    """cv_pp_run reports the TRUE per-tile counts; anything beyond the handle's capacity was not written."""
+    max_inst = recs.shape[1]
+    if (n_recs_host > max_inst).any():
+        b = int(np.argmax(n_recs_host))
+        raise CapacityError(f"tile {b} of the batch has {int(n_recs_host[b])} instances but the post-processing handle holds "
+                            f"{max_inst} records per tile: cellvit_amd.postproc.set_capacity(inst_div=...) and re-run")
+    if contours is not None and (n_pts_host > contours.shape[1]).any():
+        b = int(np.argmax(n_pts_host))
+        raise CapacityError(f"tile {b} of the batch needs {int(n_pts_host[b])} contour points but the post-processing handle "
+                            f"holds {contours.shape[1]} per tile: cellvit_amd.postproc.set_capacity(pts_div=...) and re-run")
+
+
 def records_to_dicts(recs: torch.Tensor, n_recs: torch.Tensor, contours: Optional[torch.Tensor],
-                     n_pts: torch.Tensor) -> List[dict]:
+                     n_pts: torch.Tensor, return_index: bool = False):
     """Device record arrays -> the reference's per-tile dicts (post_proc:126-151).  This is the point
-    where cell records leave the device (the writer / geojson step)."""
+    where cell records leave the device (the writer / geojson step).  With ``return_index`` also returns, per tile,
+    the record slot of every dict entry (in dict order) — the row of that cell in cv_pool_tokens' output."""
     nr = n_recs.cpu().numpy()
     npt = n_pts.cpu().numpy()
-    out = []
+    check_capacity(recs, nr, contours, npt)
+    out, index = [], []
     for b in range(recs.shape[0]):
         n = int(nr[b])
         raw = recs[b, :n].cpu().numpy().tobytes()
         arr = (_lib.cv_instance * n).from_buffer_copy(raw) if n else []
         pts = contours[b, : int(npt[b])].cpu().numpy() if contours is not None else None
-        d = {}
-        for r in arr:
+        d, idx = {}, []
+        for slot, r in enumerate(arr):
             if pts is not None and r.contour_len < 3:      # "< 3 points dont make a contour" (post_proc:113-116)
                 continue
             d[int(r.id)] = {
@@ -101,8 +135,45 @@ def records_to_dicts(recs: torch.Tensor, n_recs: torch.Tensor, contours: Optiona
                 "type_prob": float(r.type_prob),
                 "type": int(r.type),
             }
+            idx.append(slot)
         out.append(d)
+        index.append(idx)
+    return (out, index) if return_index else out
+
+
+def argmax_channels(x: torch.Tensor) -> torch.Tensor:
+    """torch.argmax(x, dim=1) of an fp32 BCHW map as a HIP kernel (first maximum) -> u8 [B,H,W] on the device."""
+    if not x.is_cuda:
+        raise RuntimeError("cellvit_amd runs on the MI355X only (no CPU fallback)")
+    x = x.contiguous().float()
+    B, Cn, H, W = x.shape
+    out = torch.empty((B, H, W), device=x.device, dtype=torch.uint8)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cv_op_argmax_nchw(x.data_ptr(), out.data_ptr(), B, Cn, H, W,
+                                                 C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
     return out
+
+
+def pool_cell_tokens(tokens: torch.Tensor, recs: torch.Tensor, n_recs: torch.Tensor, patch_size: int = 16
+                     ) -> Tuple[torch.Tensor, np.ndarray]:
+    """Cell-token pooling of the inference CLI (cell_detection.py:396-409) for every instance record of a batch, on
+    the device: tokens [B, D, gh, gw] (the `tokens` entry of forward) -> (fp32 [sum n_recs, D] device tensor, host
+    int64 [B] row offset of each tile).  One kernel launch, no per-cell host round trip."""
+    B, D, gh, gw = tokens.shape
+    tok_nhwc = tokens.permute(0, 2, 3, 1).contiguous().float()       # a view of forward's NHWC buffer: no copy
+    nr = n_recs.cpu().numpy().astype(np.int64)
+    max_inst = recs.shape[1]
+    nr = np.minimum(nr, max_inst)
+    off = np.concatenate([[0], np.cumsum(nr)[:-1]]).astype(np.int64)
+    total, max_n = int(nr.sum()), int(nr.max()) if len(nr) else 0
+    out = torch.empty((total, D), device=tokens.device, dtype=torch.float32)
+    if total:
+        off_dev = torch.from_numpy(off).to(tokens.device)
+        with torch.cuda.device(tokens.device):
+            _lib.check(_lib.load().cv_pool_tokens(tok_nhwc.data_ptr(), B, gh, gw, D, int(patch_size), recs.data_ptr(),
+                                                  max_inst, n_recs.data_ptr(), off_dev.data_ptr(), max_n, out.data_ptr(),
+                                                  C.c_void_p(torch.cuda.current_stream(tokens.device).cuda_stream)))
+    return out, off
 
 
 def _params(magnification: int, gt: bool = False) -> Tuple[int, int]:
@@ -144,13 +215,19 @@ class DetectionCellPostProcessor:
         return inst[0].cpu().numpy(), d
 
 
-def calculate_instance_map(predictions: dict, num_nuclei_classes: int, magnification: Literal[20, 40] = 40
+def calculate_instance_map(predictions: dict, num_nuclei_classes: int, magnification: Literal[20, 40] = 40,
+                           argmax_planes: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
                            ) -> Tuple[torch.Tensor, List[dict]]:
     """cellvit.py:332-383: predictions (BCHW, softmax or raw logits — only the argmax is consumed) ->
-    (instance maps [B,H,W] float32 on the host like the reference, list of per-image nucleus dicts)."""
+    (instance maps [B,H,W] float32 on the host like the reference, list of per-image nucleus dicts).
+    ``argmax_planes`` = (binary, type) u8 planes written by the forward kernels for exactly these maps; without them
+    the channel argmax (cellvit.py:366-374) runs as a HIP kernel on the given maps."""
     object_size, k_size = _params(magnification)
-    binm = torch.argmax(predictions["nuclei_binary_map"], dim=1).to(torch.uint8)
-    typ = torch.argmax(predictions["nuclei_type_map"], dim=1).to(torch.uint8)
+    if argmax_planes is not None:
+        binm, typ = argmax_planes
+    else:
+        binm = argmax_channels(predictions["nuclei_binary_map"])
+        typ = argmax_channels(predictions["nuclei_type_map"])
     hv = predictions["hv_map"]
     inst, recs, n_recs, contours, n_pts = postprocess_device(binm, typ, hv, num_nuclei_classes, object_size, k_size)
     return inst.float().cpu(), records_to_dicts(recs, n_recs, contours, n_pts)

@@ -17,8 +17,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-# record layout (int32 columns / float64 columns)
-I_ROW, I_COL, I_RMIN, I_CMIN, I_RMAX, I_CMAX, I_TYPE, I_STATUS, I_EDGE, I_NPIX, I_CLEN, I_ID = range(12)
+# record layout (int32 columns / float64 columns); bbox / centroid / contour in TILE coordinates (the global offset is a
+# function of (row, col), cell_detection.py:341-359, and is re-applied by whoever consumes the records)
+I_ROW, I_COL, I_RMIN, I_CMIN, I_RMAX, I_CMAX, I_TYPE, I_STATUS, I_EDGE, I_TILE, I_CLEN, I_ID = range(12)
 F_CX, F_CY, F_PROB = range(3)
 N_ICOL, N_FCOL = 12, 3
 
@@ -65,6 +66,25 @@ def cell_status(bbox: np.ndarray, patch_size: int = 1024, margin: int = 64) -> i
     return None   # unreachable for well-formed boxes (mirrors the reference's fall-through)
 
 
+def cell_status_array(bbox: np.ndarray, patch_size: int = 1024, margin: int = 64) -> np.ndarray:
+    """Vectorised `cell_status` for bbox [n, 4] = (rmin, cmin, rmax, cmax): int32 [n]."""
+    bbox = np.asarray(bbox).reshape(-1, 4)
+    lo, hi = margin, patch_size - margin
+    mid = ~((bbox.max(1) > hi) | (bbox.min(1) < lo))
+    top, left = bbox[:, 0] < lo, bbox[:, 1] < lo
+    down, right = bbox[:, 2] > hi, bbox[:, 3] > hi
+    st = np.select(
+        [mid, top & left, top & right, top, right & down, right, down & left, down, left],
+        [0, 1, 3, 2, 5, 4, 7, 6, 8], default=-1).astype(np.int32)
+    return st
+
+
+def cell_edge_array(bbox: np.ndarray, patch_size: int = 1024) -> np.ndarray:
+    """`np.max(bbox) == patch_size or np.min(bbox) == 0` (cell_detection.py:380) for bbox [n, 4]: bool [n]."""
+    bbox = np.asarray(bbox).reshape(-1, 4)
+    return (bbox.max(1) == patch_size) | (bbox.min(1) == 0)
+
+
 _EDGE_TABLE = {   # get_edge_patch (cell_detection.py:877-902): position -> neighbour tile offsets (drow, dcol)
     (1, 0, 0, 0): [(-1, 0)], (1, 1, 0, 0): [(-1, 0), (-1, 1), (0, 1)], (0, 1, 0, 0): [(0, 1)],
     (0, 1, 1, 0): [(0, 1), (1, 1), (1, 0)], (0, 0, 1, 0): [(1, 0)], (0, 0, 1, 1): [(1, 0), (1, -1), (0, -1)],
@@ -88,7 +108,7 @@ def pack_margin_records(tile_dict: dict, row: int, col: int, patch_size: int = 1
         bb = c["bbox"]
         edge = int(np.max(bb) == patch_size or np.min(bb) == 0)
         cont = c["contour"] if c.get("contour") is not None else np.zeros((0, 2), np.int32)
-        irows.append([row, col, bb[0, 0], bb[0, 1], bb[1, 0], bb[1, 1], c["type"], st, edge, 0, len(cont), cid])
+        irows.append([row, col, bb[0, 0], bb[0, 1], bb[1, 0], bb[1, 1], c["type"], st, edge, c.get("tile", 0), len(cont), cid])
         frows.append([c["centroid"][0], c["centroid"][1], c["type_prob"]])
         contours.append(np.asarray(cont, np.int32).reshape(-1, 2))
     ir = np.asarray(irows, np.int32).reshape(-1, N_ICOL)
@@ -114,7 +134,8 @@ def _all_gather_var(t: torch.Tensor, group=None) -> List[torch.Tensor]:
 
 def all_gather_margin_records(ir: np.ndarray, fr: np.ndarray, ct: np.ndarray, device=None, group=None):
     """Exchange the margin-cell records of all ranks (rank order preserved).  Returns the concatenated
-    (int32 [N,12], float64 [N,3], int32 [M,2]) arrays; contour slices follow the record order."""
+    (int32 [N,12], float64 [N,3], int32 [M,2]) arrays; contour slices follow the record order.
+    `device`: where the exchange buffers live — a cuda device under backend "nccl" (RCCL over xGMI), cpu under gloo."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return ir, fr, ct
     dev = device or torch.device("cpu")
@@ -123,3 +144,25 @@ def all_gather_margin_records(ir: np.ndarray, fr: np.ndarray, ct: np.ndarray, de
     parts_c = _all_gather_var(torch.from_numpy(np.ascontiguousarray(ct)).to(dev), group)
     cat = lambda ps: torch.cat(ps).cpu().numpy()   # noqa: E731
     return cat(parts_i), cat(parts_f), cat(parts_c)
+
+
+def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
+    """all-gatherv of a [n, ...] tensor along dim 0 (rank order); identity without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    return torch.cat(_all_gather_var(t.contiguous(), group))
+
+
+def canonical_order(ir: np.ndarray) -> np.ndarray:
+    """Permutation that sorts gathered records by tile index (stable): the order a single process walking the slide's
+    row-major tile list produces, whatever the world size and shard layout were."""
+    return np.argsort(ir[:, I_TILE], kind="stable")
+
+
+def reorder_records(ir: np.ndarray, fr: np.ndarray, ct: np.ndarray, perm: np.ndarray):
+    """Apply a record permutation to (ir, fr) and rebuild the flat contour array in the new record order."""
+    lens = ir[:, I_CLEN].astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]) if len(lens) else np.zeros(0, np.int64)
+    parts = [ct[offs[i]:offs[i] + lens[i]] for i in perm]
+    ct2 = np.concatenate(parts).astype(np.int32) if parts else np.zeros((0, 2), np.int32)
+    return ir[perm], fr[perm], ct2

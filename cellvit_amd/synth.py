@@ -41,7 +41,7 @@ def synth_nuclei_maps(tile_idx: int, size: int = 1024, n_cells: int = 800, n_typ
     ids = np.unique(inst)
     ids = ids[ids > 0]
     for i in ids:
-        ys, xs = np.nonzero(inst == i) if size <= 256 else _nz_fast(inst, i)
+        ys, xs = np.nonzero(inst == i)
         cy, cx = int(ys.mean() + 0.5), int(xs.mean() + 0.5)
         ox = (xs - cx).astype(np.float32)
         oy = (ys - cy).astype(np.float32)
@@ -59,8 +59,3 @@ def synth_nuclei_maps(tile_idx: int, size: int = 1024, n_cells: int = 800, n_typ
     tnoise = rng.integers(0, n_types, size=(H, W)).astype(np.uint8)
     tmap = np.where(flip & fg, tnoise, tmap).astype(np.uint8)
     return tmap, fg.astype(np.uint8), hv.astype(np.float32), inst
-
-
-def _nz_fast(inst, i):
-    ys, xs = np.nonzero(inst == i)
-    return ys, xs

@@ -71,6 +71,9 @@ typedef struct cv_outputs {
 } cv_outputs;
 
 const char* cv_last_error(void);
+/* 1 if the library was built with -DCVA_ABLATION (experiment switches CVA_* honoured, incl. work-skipping *_DBG
+ * instantiations); 0 for the production build, which ignores the environment.  bench.py refuses ablation builds.   */
+int cv_build_is_ablation(void);
 
 /* nn.Module construction — cellvit.py:57-151 / 514-572. */
 int cv_create(const cv_config* cfg, cv_handle** out);
@@ -101,6 +104,12 @@ int cv_set_derived(cv_handle* h, const char* name, const float* host_ptr, const 
 /* CellViT.forward(x, retrieve_tokens) — cellvit.py:153-210 (ViT), :586-644 (SAM).
  * x_dev: fp32 NCHW [B,3,H,W] normalised tile batch on the device.                                     */
 int cv_forward(cv_handle* h, const float* x_dev, int B, int H, int W, const cv_outputs* out, void* stream);
+
+/* The same forward on the RAW tile: x_u8 uint8 NHWC [B,H,W,3] on the device.  The reference's inference transform
+ * (T.ToTensor + T.Normalize(mean, std), cell_detection.py:214-227: (u8 / 255 - mean[c]) / std[c] in fp32) is evaluated
+ * inside the two kernels that read the image (patch matrix, decoder-0 NHWC loader); no normalised copy reaches HBM.     */
+int cv_forward_u8(cv_handle* h, const uint8_t* x_u8, const float* mean3, const float* std3, int B, int H, int W,
+                  const cv_outputs* out, void* stream);
 
 /* Debug taps (synchronises): copy a named intermediate of the LAST forward to host memory as fp32.
  * names: "tokens0", "block<i>", "z<1..4>", "skip<0..3>".  Returns the element count in *n_out.        */
@@ -138,6 +147,12 @@ int cv_op_attention(int dtype, const void* x, const void* Wqkv, const float* bqk
                     const float* tab_w, void* out, int B, int gh, int gw, int has_cls, int heads,
                     int D, int win, void* stream);
 
+/* argmax over dim 1 of an fp32 NCHW map -> u8 [B,H,W], first maximum (torch.argmax of cellvit.py:366-374).           */
+int cv_op_argmax_nchw(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream);
+/* u8 NHWC [B,H,W,3] -> fp32 NCHW [B,3,H,W], the inference transform of cell_detection.py:214-227 as a stand-alone op.   */
+int cv_op_normalize_u8(const uint8_t* x_u8, const float* mean3, const float* std3, float* out, int B, int H, int W,
+                       void* stream);
+
 /* ---- per-tile instance post-processing ------------------------------------------------------------
  * Replaces DetectionCellPostProcessor.post_process_cell_segmentation + __proc_np_hv
  *   (cell_segmentation/utils/post_proc_cellvit.py:67-153, 155-249) and the per-sample glue of
@@ -169,6 +184,12 @@ int cv_pp_run(cv_pp* pp, const uint8_t* bin_argmax, const uint8_t* type_argmax, 
 int cv_pp_run_params(cv_pp* pp, const uint8_t* bin_argmax, const uint8_t* type_argmax, const float* hv, int B,
                      int object_size, int ksize, int nr_types, int32_t* inst_map, cv_instance* recs,
                      int32_t* n_recs, int32_t* contours, int32_t* n_pts, void* stream);
+/* Cell-token pooling of the inference CLI (cell_detection.py:396-409) on the device record arrays of cv_pp_run:
+ * out[rec_offset[b] + i, :] = mean over tokens_nhwc[b, floor(rmin/p):ceil(rmax/p), floor(cmin/p):ceil(cmax/p), :] for
+ * record i < n_recs[b] (indices cast to uint8 as the reference does).  rec_offset: int64 [B] device (exclusive prefix
+ * of n_recs, or any layout the caller wants), max_n = max_b n_recs[b] (grid size).  out fp32 [sum n_recs, D].          */
+int cv_pool_tokens(const float* tokens_nhwc, int B, int gh, int gw, int D, int patch_size, const cv_instance* recs,
+                   int max_inst, const int32_t* n_recs, const int64_t* rec_offset, int max_n, float* out, void* stream);
 /* Debug taps of the last run (synchronises): "dist" f64 [B,H,W], "marker" i32 [B,H,W], "blb" u8 [B,H,W]. */
 int cv_pp_debug_read(cv_pp* pp, const char* name, void* host_dst, size_t bytes);
 

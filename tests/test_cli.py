@@ -68,6 +68,152 @@ def test_polygon_geometry_exact():
     assert (fa, fb, aa, ab) == (0.5, 0.5, 48.0, 48.0)
 
 
+def test_geojson_types_sorted_like_the_reference():
+    cells = [_cell(10, 10, 5, 0, 0, status=0), _cell(30, 30, 5, 0, 0, status=0), _cell(60, 60, 5, 0, 0, status=0)]
+    cells[0]["type"], cells[1]["type"], cells[2]["type"] = 4, 2, 3
+    for polygons in (True, False):
+        feats = CD.convert_geojson(cells, polygons)
+        assert [f["properties"]["classification"]["name"] for f in feats] == ["Inflammatory", "Connective", "Dead"]
+        assert feats[0]["geometry"]["type"] == ("MultiPolygon" if polygons else "MultiPoint")
+        assert len({f["id"] for f in feats}) == 3
+    ring = CD.convert_geojson(cells, True)[0]["geometry"]["coordinates"][0][0]
+    assert ring[0] == ring[-1] and len(ring) == 5          # closed ring (:566-568)
+
+
+def test_cell_status_array_matches_scalar_rules():
+    from cellvit_amd import sharding as S
+    rng = np.random.default_rng(3)
+    r0 = rng.integers(0, 1000, 4000); c0 = rng.integers(0, 1000, 4000)
+    r1 = np.minimum(r0 + rng.integers(1, 80, 4000), 1024); c1 = np.minimum(c0 + rng.integers(1, 80, 4000), 1024)
+    bb = np.stack([r0, c0, r1, c1], 1)
+    st = S.cell_status_array(bb)
+    ed = S.cell_edge_array(bb)
+    for k in range(len(bb)):
+        b = bb[k].reshape(2, 2)
+        assert st[k] == S.cell_status(b), (b, st[k])
+        assert bool(ed[k]) == bool(np.max(b) == 1024 or np.min(b) == 0)
+
+
+# ---- a synthetic 3 x 3-tile slide: true cells in slide coordinates, seen by every tile whose extent they intersect ----
+def _synthetic_slide_tiles(seed=0, grid=3, n_cells=700):
+    from cellvit_amd import sharding as S
+    rng = np.random.default_rng(seed)
+    lo = S.global_offset(0, 0, 1024, 1, 64)[0]
+    hi = S.global_offset(grid - 1, grid - 1, 1024, 1, 64)[0] + 1024
+    cy = rng.integers(lo, hi - 40, n_cells); cx = rng.integers(lo, hi - 40, n_cells)
+    sz = rng.integers(8, 40, n_cells); ty = rng.integers(1, 6, n_cells)
+    tiles = {}
+    for row in range(grid):
+        for col in range(grid):
+            xg, yg = S.global_offset(row, col, 1024, 1, 64)      # (row offset, col offset)
+            d, nid = {}, 0
+            for k in range(n_cells):
+                r0, c0, r1, c1 = cy[k] - xg, cx[k] - yg, cy[k] + sz[k] - xg, cx[k] + sz[k] - yg
+                r0c, c0c, r1c, c1c = max(r0, 0), max(c0, 0), min(r1, 1024), min(c1, 1024)
+                if r1c - r0c < 3 or c1c - c0c < 3:
+                    continue
+                nid += 1 + int(rng.integers(0, 2))                  # ids with gaps, as the watershed leaves them
+                cont = np.array([[c0c, r0c], [c0c, r1c - 1], [c1c - 1, r1c - 1], [c1c - 1, r0c]], np.int32)
+                d[nid] = {"bbox": np.array([[r0c, c0c], [r1c, c1c]]), "centroid": np.array([(c0c + c1c) / 2, (r0c + r1c) / 2]),
+                          "contour": cont, "type_prob": 0.5 + 0.001 * k, "type": int(ty[k])}
+            tiles[(row, col)] = d
+    return tiles
+
+
+def _slide_cells_of(tiles, tile_ids, grid=3):
+    from cellvit_amd import sharding as S
+    parts = []
+    for t in tile_ids:
+        row, col = divmod(t, grid)
+        irs, frs, cts = [], [], []
+        for cid, c in tiles[(row, col)].items():
+            bb = c["bbox"]
+            irs.append([row, col, bb[0, 0], bb[0, 1], bb[1, 0], bb[1, 1], c["type"], S.cell_status(bb),
+                        int(np.max(bb) == 1024 or np.min(bb) == 0), t, len(c["contour"]), cid])
+            frs.append([c["centroid"][0], c["centroid"][1], c["type_prob"]])
+            cts.append(c["contour"])
+        n = len(irs)
+        tok = torch.arange(n, dtype=torch.float32)[:, None] + 1000.0 * t + torch.zeros((n, 4))
+        parts.append(CD.SlideCells(np.asarray(irs, np.int32).reshape(-1, 12), np.asarray(frs, np.float64).reshape(-1, 3),
+                                   np.concatenate(cts).astype(np.int32) if cts else np.zeros((0, 2), np.int32), tok))
+    return CD.SlideCells.concat(parts)
+
+
+def _stitch_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from cellvit_amd import sharding as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tiles = _synthetic_slide_tiles()
+    local = _slide_cells_of(tiles, S.shard_tiles(9, rank, world, block=2))
+    allc, dicts = CD.finalize_slide(local, 1024, 1, 64)
+    q.put((rank, dicts, allc.tokens.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_stitch_equals_world1():
+    """Sharding the slide over 2 ranks (block-cyclic, gloo) must give exactly the single-process cell set, in the same
+    order, with the same token rows: only margin records are exchanged and ONE global stitch runs."""
+    import socket
+    import torch.multiprocessing as mp
+    tiles = _synthetic_slide_tiles()
+    ref_all, ref_dicts = CD.finalize_slide(_slide_cells_of(tiles, list(range(9))), 1024, 1, 64)
+    n_before = sum(len(d) for d in tiles.values())
+    assert 0 < len(ref_dicts) < n_before                     # duplicates in the overlap margins were removed
+    assert any(c["cell_status"] != 0 for c in ref_dicts) and any(c["edge_position"] for c in ref_dicts)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stitch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, dicts, tok in res:
+        assert dicts == ref_dicts
+        assert np.array_equal(tok, ref_all.tokens.numpy())
+
+
+def test_cells_pt_wire_format(tmp_path):
+    """cells.pt is the reference's CellGraphDataWSI dataclass, pickled under the reference's module path
+    (cell_detection.py:469-475, cell_graph_datamodel.py:18-26): x, positions, metadata, contours."""
+    import pickletools
+    from cellvit_amd.datamodel import make_cell_graph
+    g = make_cell_graph(x=torch.ones(3, 8), positions=torch.zeros(3, 2), contours=[torch.zeros(4, 2)] * 3,
+                        metadata={"wsi_metadata": {"a": 1}, "nuclei_types": {"Background": 0}})
+    torch.save(g, tmp_path / "cells.pt")
+    back = torch.load(tmp_path / "cells.pt", weights_only=False)
+    assert type(back).__name__ == "CellGraphDataWSI"
+    assert type(back).__module__ == "cell_segmentation.datasets.cell_graph_datamodel"
+    assert [f for f in back.__dataclass_fields__] == ["x", "positions", "metadata", "contours"]
+    assert torch.equal(back.x, g.x) and len(back.contours) == 3 and back.metadata["wsi_metadata"] == {"a": 1}
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/cell_segmentation"), reason="reference tree not present")
+def test_cells_pt_loads_with_the_reference_classes(tmp_path):
+    """Development container only: a file written here unpickles in a fresh interpreter that has ONLY the reference on its
+    path, as an instance of the reference's own dataclass."""
+    import subprocess
+    import sys
+    from cellvit_amd.datamodel import make_cell_graph
+    g = make_cell_graph(x=torch.arange(6.).reshape(2, 3), positions=torch.ones(2, 2), contours=[torch.zeros(3, 2)] * 2,
+                        metadata={"nuclei_types": {"Background": 0}})
+    torch.save(g, tmp_path / "cells.pt")
+    code = ("import sys, torch; sys.path.insert(0, '/root/reference');"
+            "from cell_segmentation.datasets.cell_graph_datamodel import CellGraphDataWSI;"
+            f"g = torch.load(r'{tmp_path / 'cells.pt'}', weights_only=False);"
+            "assert isinstance(g, CellGraphDataWSI), type(g);"
+            "assert g.x.shape == (2, 3) and len(g.contours) == 2 and g.positions.sum() == 4; print('REF-OK')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert "REF-OK" in r.stdout, r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_cli_end_to_end_tiny_slide(tmp_path):
     from PIL import Image
@@ -102,3 +248,41 @@ def test_cli_end_to_end_tiny_slide(tmp_path):
         assert {"bbox", "centroid", "contour", "type_prob", "type", "patch_coordinates", "cell_status",
                 "offset_global", "edge_position"} <= set(c.keys())
     assert (out / "cell_detection.json").exists() and (out / "cells.geojson").exists()
+    # cells.pt: the reference's container, one token row / position / contour per written cell
+    g = torch.load(out / "cells.pt", weights_only=False)
+    assert type(g).__name__ == "CellGraphDataWSI" and g.x.shape == (len(cells["cells"]), 384)
+    assert g.positions.shape == (len(cells["cells"]), 2) and len(g.contours) == len(cells["cells"])
+    assert np.allclose(g.positions.numpy(), np.array([c["centroid"] for c in cells["cells"]], dtype=np.float32))
+
+    # the tile loop against an independent route through the tested public API: normalise op -> forward ->
+    # calculate_instance_map (planes) -> reference token-pooling formula
+    inf = CD.CellSegmentationInference(str(tmp_path / "ckpt.pth"), 0)
+    wsi = CD.PatchedSlide("slide", str(slide))
+    local, processed, stats = inf.run_tiles(wsi, [0, 1], batch_size=2)
+    assert processed == ["0_0", "0_1"] and stats["tiles"] == 2
+    u8 = torch.from_numpy(np.stack([wsi.load_patch_image(n) for n in wsi.patches_list]))
+    pred = inf.model.forward(inf._normalize(u8), retrieve_tokens=True)
+    _, dicts = inf.model.calculate_instance_map(pred, 40)
+    tokens = pred["tokens"].cpu()
+    from cellvit_amd import sharding as S
+    k = 0
+    for t, d in enumerate(dicts):
+        for cid, c in d.items():
+            if c["type"] == 0:
+                continue
+            i, f = local.ir[k], local.fr[k]
+            assert (int(i[S.I_TILE]), int(i[S.I_ID]), int(i[S.I_TYPE])) == (t, cid, c["type"])
+            assert np.array_equal(i[S.I_RMIN:S.I_CMAX + 1], c["bbox"].ravel())
+            assert f[S.F_CX] == c["centroid"][0] and f[S.F_CY] == c["centroid"][1] and f[S.F_PROB] == c["type_prob"]
+            assert int(i[S.I_STATUS]) == S.cell_status(c["bbox"]) and int(i[S.I_CLEN]) == len(c["contour"])
+            bb = c["bbox"] / 16
+            bb[0, :] = np.floor(bb[0, :]); bb[1, :] = np.ceil(bb[1, :]); bb = bb.astype(np.uint8)
+            want = tokens[t, :, bb[0, 0]:bb[1, 0], bb[0, 1]:bb[1, 1]].reshape(384, -1).T.mean(0)
+            assert torch.allclose(local.tokens[k].cpu(), want, rtol=1e-5, atol=1e-5)
+            k += 1
+    assert k == len(local)
+    offs, lens = local.contour_slices()
+    flat = np.concatenate([c["contour"] for d in dicts for c in d.values() if c["type"] != 0]) if k else np.zeros((0, 2))
+    assert np.array_equal(local.ct, flat)
+    print(f"\n[cli] {k} cells from 2 tiles match the API route; {len(cells['cells'])} written after stitching; "
+          f"{stats['tiles'] / stats['t_loop']:.1f} tiles/s in the tile loop")

@@ -10,7 +10,8 @@ from helpers import CASES, compare_outputs, load_case
 pytestmark = pytest.mark.gpu
 
 ATOL_F32 = 1e-3          # north_star: "HV/type logits within 1e-3 fp32"
-ATOL_F16 = 6e-2          # fp16 operands through up to 32 blocks + 4 decoder stages (reported)
+ATOL_F16 = 1e-2          # fp16 operands through up to 32 blocks + 4 decoder stages: measured 1.2e-3 ... 2.8e-3
+ARGMAX_BIN, ARGMAX_TYPE = 0.999, 0.998    # measured >= 0.9993
 
 
 def _model(cfg, sd, dtype):
@@ -82,8 +83,8 @@ def test_forward_fp16_error_statistics(name):
     print(f"\n[{name} fp16] (max abs, mean abs) / argmax agreement: {stats}")
     for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
         assert stats[k][0] < ATOL_F16, (k, stats[k])
-    assert stats["nuclei_binary_map_argmax_agree"] > 0.99
-    assert stats["nuclei_type_map_argmax_agree"] > 0.98
+    assert stats["nuclei_binary_map_argmax_agree"] >= ARGMAX_BIN
+    assert stats["nuclei_type_map_argmax_agree"] >= ARGMAX_TYPE
 
 
 def test_forward_fp32_samh_1024_crops():
@@ -115,7 +116,7 @@ def test_autocast_selects_fp16_engine():
     with torch.autocast(device_type="cuda", dtype=torch.float16):
         out = m(x.cuda())
     from cellvit_amd import _lib
-    assert list(m._engines.keys()) == [_lib.DTYPE_F16]
+    assert [k[1] for k in m._engines.keys()] == [_lib.DTYPE_F16]
     assert np.abs(out["hv_map"].cpu().numpy() - gold["hv_map"]).max() < ATOL_F16
 
 
@@ -143,7 +144,8 @@ def test_samh_1024_fp16_full_size_properties():
         d = (a[k][0] - out1[k][0]).abs().max().item()
         assert d < ATOL_F16, (k, d)
     agree = (a["nuclei_type_map"][0].argmax(0) == out1["nuclei_type_map"][0].argmax(0)).float().mean().item()
-    assert agree > 0.995, agree
+    print(f"[samh_1024 fp16] batch-of-2 vs single tile: type argmax agreement {agree:.5f}")
+    assert agree >= ARGMAX_TYPE, agree
     # bench.py's default batch (32 tiles: decoder activations of 8.6 GB, i.e. byte offsets far beyond 32 bits): the LAST and a
     # middle tile of the batch must reproduce the small-batch results of the same tiles
     keep = {k: (out1[k][0].clone(), a[k][1].clone()) for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map")}
@@ -159,7 +161,8 @@ def test_samh_1024_fp16_full_size_properties():
             assert d < ATOL_F16, (k, idx, d)
     for idx in (17, 31):
         agree = (big["nuclei_type_map"][idx].argmax(0) == keep["nuclei_type_map"][0].argmax(0)).float().mean().item()
-        assert agree > 0.995, (idx, agree)
+        print(f"[samh_1024 fp16] tile {idx} of a batch of 32 vs single tile: type argmax agreement {agree:.5f}")
+        assert agree >= ARGMAX_TYPE, (idx, agree)
 
 
 @pytest.mark.parametrize("tile,B", [(512, 4), (256, 16)])
@@ -179,4 +182,36 @@ def test_samh_fp16_vs_fp32_engine_other_geometries(tile, B):
         d = (a[k].float() - b[k].float()).abs().max().item()
         assert d < ATOL_F16, (k, d)
     agree = (a["nuclei_type_map"].argmax(1) == b["nuclei_type_map"].argmax(1)).float().mean().item()
-    assert agree > 0.99, agree
+    agree_b = (a["nuclei_binary_map"].argmax(1) == b["nuclei_binary_map"].argmax(1)).float().mean().item()
+    print(f"\n[samh {tile}^2 x{B}] fp16 vs fp32 engine: argmax agreement type {agree:.5f} binary {agree_b:.5f}")
+    assert agree >= ARGMAX_TYPE and agree_b >= ARGMAX_BIN, (agree, agree_b)
+
+
+def test_samh_1024_fp16_vs_fp32_full_map_argmax_agreement():
+    """Full 1024^2 SAM-H tile (BASELINE.json configs[2]): every pixel of every output map of the production fp16 engine
+    against the exact-fp32 engine (itself within 1e-3 of the imported reference): max-abs / mean-abs per map, argmax
+    agreement over the whole map, and a PQ-style instance-level gate on the post-processed instance maps."""
+    from cellvit_amd.metrics import panoptic_quality, remap_label
+    cfg, sd, x, _ = load_case("samh_1024")
+    m16, m32 = _model(cfg, sd, "fp16"), _model(cfg, sd, "fp32")
+    a = m16(x.cuda(), retrieve_tokens=True)
+    b = m32(x.cuda(), retrieve_tokens=True)
+    torch.cuda.synchronize()
+    rep = {}
+    for k in ("tissue_types", "nuclei_binary_map", "hv_map", "nuclei_type_map", "tokens"):
+        d = (a[k].float() - b[k].float()).abs()
+        rep[k] = (d.max().item(), d.mean().item())
+    ag_t = (a["nuclei_type_map"].argmax(1) == b["nuclei_type_map"].argmax(1)).float().mean().item()
+    ag_b = (a["nuclei_binary_map"].argmax(1) == b["nuclei_binary_map"].argmax(1)).float().mean().item()
+    print(f"\n[samh_1024 fp16 vs fp32, full maps] (max abs, mean abs): {rep}; argmax agreement type {ag_t:.5f} binary {ag_b:.5f}")
+    for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
+        assert rep[k][0] < ATOL_F16, (k, rep[k])
+    assert ag_t >= ARGMAX_TYPE and ag_b >= ARGMAX_BIN
+    ia, _ = m16.calculate_instance_map(a, 40)
+    ib, _ = m32.calculate_instance_map(b, 40)
+    ia, ib = ia[0].numpy().astype(np.int32), ib[0].numpy().astype(np.int32)
+    if ib.max() > 0 and ia.max() > 0:
+        (dq, sq, pq), _ = panoptic_quality(remap_label(ib), remap_label(ia))
+        print(f"[samh_1024 fp16 vs fp32] instance-level agreement of the post-processed maps: DQ {dq:.4f} SQ {sq:.4f} PQ {pq:.4f} "
+              f"({int(ib.max())} / {int(ia.max())} max ids)")
+        assert pq > 0.9, (dq, sq, pq)

@@ -36,3 +36,20 @@ def test_pq_hand_cases():
     assert binary_pq_batch([a, a], [a, b]) > 0.8
     with pytest.raises(AssertionError):
         panoptic_quality(a, b, -0.1)
+
+
+def test_generate_instance_nuclei_map_matches_the_imported_reference():
+    """P9 (cellvit.py:385-414): fixtures produced by the reference method itself (tools/make_golden_instmap.py)."""
+    import os
+    import torch
+    from cellvit_amd.model import CellViT256
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "instmap_cases.npz"))
+    B = int(g["n"])
+    type_preds = [{int(i): {"type": int(t)} for i, t in zip(g[f"ids{b}"], g[f"types{b}"])} for b in range(B)]
+    m = CellViT256(None, 6, 19)
+    out = m.generate_instance_nuclei_map(torch.from_numpy(g["inst"]).float(), type_preds)
+    assert out.dtype == torch.float32 and tuple(out.shape) == g["out"].shape
+    assert np.array_equal(out.numpy(), g["out"])
+    painted = sum(len(np.unique(g["out"][b])) - 1 for b in range(B))
+    assert painted > 60                                              # and some instances deliberately absent from the dicts
+    assert any(len(np.setdiff1d(np.unique(g["inst"][b])[1:], g[f"ids{b}"])) for b in range(B))
