@@ -120,7 +120,7 @@ class TilePrefetcher:
             imgs = [f.result() for f in futs]
             host = torch.empty((len(imgs),) + imgs[0].shape, dtype=torch.uint8, pin_memory=self.dev.type == "cuda")
             for i, im in enumerate(imgs):
-                host[i] = torch.from_numpy(im)
+                np.copyto(host[i].numpy(), im)
             if self._next < len(self.batches):
                 self._submit()
             yield ids, host.to(self.dev, non_blocking=True), [m.result() for m in mds]
