@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcellvit_amd.so")
 
 CV_OK, CV_ERR_INVALID, CV_ERR_HIP, CV_ERR_STATE, CV_ERR_SHAPE, CV_ERR_UNSUPPORTED, CV_ERR_MISSING = range(7)
-DTYPE_F16, DTYPE_F32 = 0, 1
+DTYPE_F16, DTYPE_F32, DTYPE_F8 = 0, 1, 2
 
 
 class cv_config(C.Structure):
@@ -52,6 +52,13 @@ SYMBOLS = {
                                      C.c_int, C.c_void_p]),
     "cv_pool_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "cv_mx8_quantize_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cv_op_linear_mx8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cv_op_layernorm_mx8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "cv_op_attention_mx8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cv_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
     "cv_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "cv_op_linear": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

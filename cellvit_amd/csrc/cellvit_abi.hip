@@ -65,8 +65,10 @@ constexpr float LN_EPS = 1e-6f;   // cellvit.py:99, 559; SAM/utils.py:39
 constexpr double BN_EPS = 1e-5;   // torch default (utils.py:37, 80)
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-inline size_t esize(int dtype) { return dtype == CV_DTYPE_F16 ? 2 : 4; }
-inline int bk_of(int dtype) { return dtype == CV_DTYPE_F16 ? Traits<half_t>::BK : Traits<float>::BK; }
+// CV_DTYPE_F8 = the fp16 engine with MX-fp8 qkv / fc1 / fc2 contractions: everything else is stored and computed as fp16
+inline bool is_f32(int dtype) { return dtype == CV_DTYPE_F32; }
+inline size_t esize(int dtype) { return is_f32(dtype) ? 4 : 2; }
+inline int bk_of(int dtype) { return is_f32(dtype) ? Traits<float>::BK : Traits<half_t>::BK; }
 
 struct HostTensor {
     std::vector<float> data;
@@ -74,7 +76,8 @@ struct HostTensor {
     size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
 };
 
-struct LinearW { void* W = nullptr; float* bias = nullptr; int N = 0, K = 0, ldw = 0; };
+struct LinearW { void* W = nullptr; float* bias = nullptr; int N = 0, K = 0, ldw = 0;
+                 void* W8 = nullptr; void* S8 = nullptr; };   // fp8 engine: e4m3 bytes [N, K] + E8M0 scale blocks (gemm.h)
 struct ConvW { void* W = nullptr; float* bias = nullptr; int Cout = 0, Ctot = 0, K = 0, ldw = 0; int relu = 1; int Cin_real = 0; };
 struct ConvTW { void* W = nullptr; float* bias4 = nullptr; int Cin = 0, Cout = 0, ldw = 0; };
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
@@ -121,6 +124,7 @@ struct cv_handle {
     void *patchA = nullptr, *xn = nullptr, *Q = nullptr, *K = nullptr, *Vt_win = nullptr, *Vt_glob = nullptr,
          *attn_out = nullptr, *hidden = nullptr, *z[4] = {nullptr, nullptr, nullptr, nullptr}, *img8 = nullptr,
          *skip[4] = {nullptr, nullptr, nullptr, nullptr}, *S[3] = {nullptr, nullptr, nullptr}, *small_T = nullptr;
+    void *xn8 = nullptr, *xn_sca = nullptr, *xn_scw = nullptr, *hidden8 = nullptr, *hidden_sc = nullptr;   // fp8 engine
     float *resid = nullptr, *relh = nullptr, *relw = nullptr, *neck_f32a = nullptr, *neck_f32b = nullptr,
           *small_f32 = nullptr, *dbg_blocks = nullptr, *dbg_tokens0 = nullptr;
     size_t ws_bytes = 0;
@@ -159,7 +163,7 @@ int upload_matrix(cv_handle* h, const float* src, int rows, int K, int ldw, void
     void* p;
     int rc = dev_alloc(h->allocs, &p, n * esize(dt));
     if (rc) return rc;
-    if (dt == CV_DTYPE_F16) {
+    if (!is_f32(dt)) {
         std::vector<half_t> tmp(n, (half_t)0.f);
         for (int r = 0; r < rows; ++r)
             for (int k = 0; k < K; ++k) tmp[(size_t)r * ldw + k] = (half_t)src[(size_t)r * K + k];
@@ -185,6 +189,72 @@ const HostTensor* find(cv_handle* h, const std::string& key, std::initializer_li
 
 #define CVA_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 #define CVA_NEED(ptr) do { if (!(ptr)) return CV_ERR_MISSING_WEIGHT; } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// OCP MX-fp8 (e4m3 elements, E8M0 scale per 32 K elements) — host side of the fp8 engine
+// ------------------------------------------------------------------------------------------------
+uint8_t f32_to_e4m3(float f) {     // round to nearest even, saturating at +-448 (0x7e); NaN -> 0x7f
+    uint32_t u; memcpy(&u, &f, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
+    if (f != f) return sign | 0x7f;
+    const double a = std::fabs((double)f);
+    if (a >= 448.0) return sign | 0x7e;
+    if (a == 0.0) return sign;
+    int e; (void)std::frexp(a, &e); e -= 1;                  // a = m * 2^e, 1 <= m < 2
+    if (e < -6) e = -6;                                      // subnormal range shares the exponent of 2^-6
+    const double step = std::ldexp(1.0, e - 3);              // 3 mantissa bits
+    const double q = std::nearbyint(a / step);               // ties to even (default rounding mode)
+    double v = q * step;
+    if (v >= 448.0) return sign | 0x7e;                      // (cannot exceed 448 for a < 448, kept for safety)
+    if (v == 0.0) return sign;
+    if (v < std::ldexp(1.0, -6)) return sign | (uint8_t)std::lround(v / std::ldexp(1.0, -9));      // subnormal: m * 2^-9
+    int e2; const double m = std::frexp(v, &e2); e2 -= 1;    // v = (2m) * 2^e2
+    const int mant = (int)std::lround((2.0 * m - 1.0) * 8.0);
+    return sign | (uint8_t)(((e2 + 7) << 3) | mant);
+}
+
+// rows x K fp32 -> e4m3 bytes [rows, K] + E8M0 scale byte per (row, 32-block): sc(row, kblock) = out index callback
+template <typename IndexFn>
+void mx8_quantize(const float* src, int rows, int K, uint8_t* data, uint8_t* scales, IndexFn index) {
+    for (int r = 0; r < rows; ++r)
+        for (int kb = 0; kb < K / 32; ++kb) {
+            const float* x = src + (size_t)r * K + kb * 32;
+            float amax = 0.f;
+            for (int j = 0; j < 32; ++j) amax = std::max(amax, std::fabs(x[j]));
+            uint32_t u; memcpy(&u, &amax, 4);
+            int sb = (int)((u >> 23) & 0xff) - 8; if (sb < 0) sb = 0;             // shared exponent floor(log2 amax) - 8, biased by 127
+            const float inv = std::ldexp(1.0f, 127 - sb);
+            for (int j = 0; j < 32; ++j) {
+                float v = x[j] * inv;
+                v = v > 448.f ? 448.f : (v < -448.f ? -448.f : v);
+                data[(size_t)r * K + kb * 32 + j] = f32_to_e4m3(v);
+            }
+            scales[index(r, kb * 32)] = (uint8_t)sb;
+        }
+}
+
+int upload_bytes(cv_handle* h, const std::vector<uint8_t>& v, void** out) {
+    void* p;
+    int rc = dev_alloc(h->allocs, &p, v.size());
+    if (rc) return rc;
+    CVA_CHECK_HIP(hipMemcpy(p, v.data(), v.size(), hipMemcpyHostToDevice));
+    *out = p;
+    return CV_OK;
+}
+
+// fp8 image of a packed nn.Linear: rows >= swap_from (the V rows of a fused qkv projection, which gemm8 runs with the
+// operands exchanged) get their scales in the A-side fragment order, all others in the W-side order (gemm.h).
+int pack_linear_mx8(cv_handle* h, const std::string& p, int N, int K, int swap_from, LinearW* out) {
+    const HostTensor* w = find(h, p + ".weight", {N, K});
+    CVA_NEED(w);
+    if (N % 256 || K % 128) { cva_set_error("fp8 engine: '%s' [%d, %d] does not tile by 256 x 128", p.c_str(), N, K); return CV_ERR_UNSUPPORTED; }
+    std::vector<uint8_t> data((size_t)N * K), sc((size_t)N * (K / 32));
+    mx8_quantize(w->data.data(), N, K, data.data(), sc.data(),
+                 [&](int r, int k) { return (size_t)mx8_scale_index(r, k, K, /*w_side=*/r < swap_from); });
+    CVA_TRY(upload_bytes(h, data, &out->W8));
+    CVA_TRY(upload_bytes(h, sc, &out->S8));
+    return CV_OK;
+}
 
 int pack_linear(cv_handle* h, const std::string& p, int N, int K, bool bias, LinearW* out) {
     const HostTensor* w = find(h, p + ".weight", {N, K});
@@ -323,6 +393,20 @@ int run_linear(const void* A, int lda, const LinearW& w, const float* res, int l
     return CV_OK;
 }
 
+// fp8 engine: out = act(A8 . W8^T + bias) (+ residual) on MX-fp8 operands.  out_mode OUT_LINEAR (out_f32 0/1) or OUT_MX8.
+int run_linear_mx8(const void* A8, const void* a_sc, int lda, const LinearW& w, const float* res, int ldres, void* out, int ldc,
+                   int out_f32, int out_mode, void* out_sc, int M, int act, hipStream_t st) {
+    GemmParams p{};
+    p.M = M; p.N = w.N; p.K = w.K; p.A = A8; p.W = w.W8; p.lda = lda; p.ldw = w.K;
+    p.a_scale = a_sc; p.w_scale = w.S8;
+    p.bias = w.bias; p.act = act; p.res = res; p.ldres = ldres;
+    p.out_mode = out_mode; p.out_f32 = out_f32; p.out = out; p.ldc = ldc; p.out_scale = out_sc;
+    ProfScope ps(KC_GEMM_LINEAR, 2.0 * M * (double)w.N * w.K, st);
+    const int rc = launch_gemm8_f8(p, st);
+    if (rc) { cva_set_error("fp8 gemm launch failed (%d): M=%d N=%d K=%d", rc, M, w.N, w.K); return rc == (int)hipErrorInvalidValue ? CV_ERR_UNSUPPORTED : CV_ERR_HIP; }
+    return CV_OK;
+}
+
 struct HeadFuse { const float* W = nullptr; const float* b = nullptr; float* logits = nullptr; uint8_t* argmax = nullptr; int nout = 0, narg = 0; };
 
 // returns CV_OK; *fused (if given) tells whether the 1x1 head ran inside the conv epilogue
@@ -375,7 +459,8 @@ int run_convT(const void* src, const ConvTW& w, void* out, int B, int Hs, int Ws
 template <typename T>
 int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, const float* tab_w, bool window,
                         void* Q, void* K, void* Vt, float* relh, float* relw, void* attn_out, int B, int gh, int gw,
-                        int has_cls, int heads, int D, int ws, hipStream_t st, bool prepadded = false) {
+                        int has_cls, int heads, int D, int ws, hipStream_t st, bool prepadded = false,
+                        const void* xn_sca = nullptr, const void* xn_scw = nullptr) {
     const int hd = D / heads, P = gh * gw, ntok = P + has_cls;
     const int nwy = window ? (gh + ws - 1) / ws : 0, nwx = window ? (gw + ws - 1) / ws : 0;
     const int L = window ? ws * ws : ntok, Lp = round_up(L, 64);
@@ -386,7 +471,12 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
     g.q_out = Q; g.k_out = K; g.vt_out = Vt;
     g.D = D; g.hd = hd; g.heads = heads; g.ntok = ntok; g.L = L; g.Lp = Lp;
     g.win = window ? ws : 0; g.gw = gw; g.gh = gh; g.nwx = nwx; g.nwy = nwy;
-    { ProfScope ps(KC_GEMM_QKV, 2.0 * g.M * (double)g.N * g.K, st); CVA_LAUNCH(launch_gemm<T>(g, A_LINEAR, st)); }
+    if (xn_sca) {      // fp8 engine: xn is the MX-fp8 image written by the LayerNorm, qkv.W8 / S8 the packed weight
+        g.W = qkv.W8; g.ldw = qkv.K; g.a_scale = xn_sca; g.a_scale_w = xn_scw; g.w_scale = qkv.S8;
+        ProfScope ps(KC_GEMM_QKV, 2.0 * g.M * (double)g.N * g.K, st);
+        const int rc8 = launch_gemm8_f8(g, st);
+        if (rc8) { cva_set_error("fp8 qkv gemm launch failed (%d)", rc8); return rc8 == (int)hipErrorInvalidValue ? CV_ERR_UNSUPPORTED : CV_ERR_HIP; }
+    } else { ProfScope ps(KC_GEMM_QKV, 2.0 * g.M * (double)g.N * g.K, st); CVA_LAUNCH(launch_gemm<T>(g, A_LINEAR, st)); }
     if (!prepadded && window && (nwy * ws != gh || nwx * ws != gw)) {
         PadKVParams pk{};
         pk.K = K; pk.Vt = Vt; pk.qkv_bias = qkv.bias; pk.B = B; pk.heads = heads; pk.hd = hd; pk.D = D; pk.L = L;
@@ -441,27 +531,37 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
     // ---- transformer blocks (F3/F4/F5) ----
     int zi = 0;
     const bool fuse_add = sizeof(T) == 2 && !h->debug && !h->no_ln_add;   // proj's residual add fused into LayerNorm 2
+    const bool f8 = sizeof(T) == 2 && c.compute_dtype == CV_DTYPE_F8;     // MX-fp8 qkv / fc1 / fc2 (BASELINE.json configs[4])
     for (int i = 0; i < c.depth; ++i) {
         const BlockW& b = h->blocks[i];
-        CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n1.g, b.n1.b, h->xn, 0, M, D, LN_EPS, st));
+        if (f8) CVA_LAUNCH(launch_layernorm_mx8(h->resid, D, nullptr, b.n1.g, b.n1.b, h->xn8, h->xn_sca, h->xn_scw, M, D, LN_EPS, st));
+        else CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n1.g, b.n1.b, h->xn, 0, M, D, LN_EPS, st));
         const bool window = !b.global;
         const bool own_kv = window && b.Kw && b.Vtw;
-        CVA_TRY(run_attention_layer<T>(h->xn, b.qkv, b.tab_h, b.tab_w, window, h->Q, own_kv ? b.Kw : h->K,
+        CVA_TRY(run_attention_layer<T>(f8 ? h->xn8 : h->xn, b.qkv, b.tab_h, b.tab_w, window, h->Q, own_kv ? b.Kw : h->K,
                                        own_kv ? b.Vtw : (window ? h->Vt_win : h->Vt_glob), h->relh, h->relw, h->attn_out, B, g.gh, g.gw,
-                                       g.has_cls, heads, D, c.window_size, st, own_kv));
+                                       g.has_cls, heads, D, c.window_size, st, own_kv, f8 ? h->xn_sca : nullptr, f8 ? h->xn_scw : nullptr));
         if (fuse_add) {
             // fp16 engine: proj writes its fp16 output (as the reference's autocast Linear does); the add into the fp32
             // residual stream rides with LayerNorm 2, which has to stream that row anyway (elementwise.hip)
             CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, nullptr, 0, 0, h->xn, D, 0, M, ACT_NONE, st));
-            CVA_LAUNCH(launch_layernorm_add(h->resid, D, h->xn, b.n2.g, b.n2.b, h->xn, M, D, LN_EPS, st));
+            if (f8) CVA_LAUNCH(launch_layernorm_mx8(h->resid, D, h->xn, b.n2.g, b.n2.b, h->xn8, h->xn_sca, nullptr, M, D, LN_EPS, st));
+            else CVA_LAUNCH(launch_layernorm_add(h->resid, D, h->xn, b.n2.g, b.n2.b, h->xn, M, D, LN_EPS, st));
         } else {
             CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st));
-            CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n2.g, b.n2.b, h->xn, 0, M, D, LN_EPS, st));
+            if (f8) CVA_LAUNCH(launch_layernorm_mx8(h->resid, D, nullptr, b.n2.g, b.n2.b, h->xn8, h->xn_sca, nullptr, M, D, LN_EPS, st));
+            else CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n2.g, b.n2.b, h->xn, 0, M, D, LN_EPS, st));
         }
-        CVA_TRY(run_linear<T>(h->xn, D, b.fc1, nullptr, 0, 0, h->hidden, hid, 0, M, ACT_GELU, st));
-        // (deferring the fc2 add into the next block's LayerNorm 1 the same way was measured neutral: K = 5120 hides more
-        //  of the epilogue, and the add costs the LayerNorm what it saves the GEMM)
-        CVA_TRY(run_linear<T>(h->hidden, hid, b.fc2, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st));
+        if (f8) {
+            // MX-fp8 MLP: fc1 quantises its GELU output on the way out (e4m3 + block scales = fc2's A operand)
+            CVA_TRY(run_linear_mx8(h->xn8, h->xn_sca, D, b.fc1, nullptr, 0, h->hidden8, hid, 0, OUT_MX8, h->hidden_sc, M, ACT_GELU, st));
+            CVA_TRY(run_linear_mx8(h->hidden8, h->hidden_sc, hid, b.fc2, h->resid, D, h->resid, D, 1, OUT_LINEAR, nullptr, M, ACT_NONE, st));
+        } else {
+            CVA_TRY(run_linear<T>(h->xn, D, b.fc1, nullptr, 0, 0, h->hidden, hid, 0, M, ACT_GELU, st));
+            // (deferring the fc2 add into the next block's LayerNorm 1 the same way was measured neutral: K = 5120 hides more
+            //  of the epilogue, and the add costs the LayerNorm what it saves the GEMM)
+            CVA_TRY(run_linear<T>(h->hidden, hid, b.fc2, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st));
+        }
         if (h->debug)
             CVA_CHECK_HIP(hipMemcpyAsync(h->dbg_blocks + (size_t)i * g.B * ntok * D, h->resid, (size_t)M * D * 4,
                                          hipMemcpyDeviceToDevice, st));
@@ -576,8 +676,12 @@ extern "C" int cv_create(const cv_config* cfg, cv_handle** out) {
     }
     const int hd = cfg->embed_dim / cfg->num_heads;
     if (hd != 64 && hd != 80) { cva_set_error("head_dim %d not built (64, 80)", hd); return CV_ERR_UNSUPPORTED; }
-    if (cfg->compute_dtype != CV_DTYPE_F16 && cfg->compute_dtype != CV_DTYPE_F32) {
+    if (cfg->compute_dtype != CV_DTYPE_F16 && cfg->compute_dtype != CV_DTYPE_F32 && cfg->compute_dtype != CV_DTYPE_F8) {
         cva_set_error("bad compute_dtype"); return CV_ERR_INVALID;
+    }
+    if (cfg->compute_dtype == CV_DTYPE_F8 && (cfg->arch != CV_ARCH_SAM || cfg->embed_dim % 256 != 0)) {
+        cva_set_error("the fp8 engine covers the SAM encoders (token count and embed_dim multiples of 256)");
+        return CV_ERR_UNSUPPORTED;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -646,6 +750,11 @@ extern "C" int cv_finalize(cv_handle* h) {
         const char* f2 = c.arch == CV_ARCH_VIT ? ".mlp.fc2" : ".mlp.lin2";
         CVA_TRY(pack_linear(h, p + f1, hid, D, true, &b.fc1));
         CVA_TRY(pack_linear(h, p + f2, D, hid, true, &b.fc2));
+        if (c.compute_dtype == CV_DTYPE_F8) {
+            CVA_TRY(pack_linear_mx8(h, p + ".attn.qkv", 3 * D, D, 2 * D, &b.qkv));
+            CVA_TRY(pack_linear_mx8(h, p + f1, hid, D, hid, &b.fc1));
+            CVA_TRY(pack_linear_mx8(h, p + f2, D, hid, D, &b.fc2));
+        }
     }
     if (c.arch == CV_ARCH_VIT) {
         CVA_TRY(pack_ln(h, "encoder.norm", D, &h->final_norm));
@@ -663,7 +772,7 @@ extern "C" int cv_finalize(cv_handle* h) {
     // shared skip decoders (cellvit.py:116-131)
     // input channels padded to 32 on the fp16 path so that the first conv runs on the halo kernel (whole 32-channel chunks);
     // 8 on the fp32 parity path (implicit GEMM, 16-byte pieces)
-    CVA_TRY(pack_conv_block(h, "decoder0.0", 3, 32, &h->dec0[0], h->cfg.compute_dtype == CV_DTYPE_F16 ? 32 : 8));
+    CVA_TRY(pack_conv_block(h, "decoder0.0", 3, 32, &h->dec0[0], is_f32(h->cfg.compute_dtype) ? 8 : 32));
     CVA_TRY(pack_conv_block(h, "decoder0.1", 32, 64, &h->dec0[1]));
     CVA_TRY(pack_deconv_block(h, "decoder1.0", D, s11, &h->dec1_t[0], &h->dec1_c[0]));
     CVA_TRY(pack_deconv_block(h, "decoder1.1", s11, s12, &h->dec1_t[1], &h->dec1_c[1]));
@@ -738,7 +847,7 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
                 PadKVParams pk{};
                 pk.K = b.Kw; pk.Vt = b.Vtw; pk.qkv_bias = b.qkv.bias; pk.B = B; pk.heads = heads; pk.hd = hd; pk.D = D; pk.L = g.Lw;
                 pk.Lp = g.Lpw; pk.win = c.window_size; pk.gw = g.gw; pk.gh = g.gh; pk.nwx = g.nwx; pk.nwy = g.nwy;
-                const int rc = dt == CV_DTYPE_F16 ? launch_pad_kv<half_t>(pk, nullptr) : launch_pad_kv<float>(pk, nullptr);
+                const int rc = !is_f32(dt) ? launch_pad_kv<half_t>(pk, nullptr) : launch_pad_kv<float>(pk, nullptr);
                 if (rc) { cva_set_error("pad_kv launch failed (%d)", rc); return CV_ERR_HIP; }
             }
             CVA_CHECK_HIP(hipDeviceSynchronize());
@@ -751,7 +860,18 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
         CVA_TRY(A((void**)&h->neck_f32b, M * c.neck_chans * 4));
     }
     CVA_TRY(A(&h->attn_out, M * D * es));
-    CVA_TRY(A(&h->hidden, M * D * c.mlp_ratio * es));
+    if (dt == CV_DTYPE_F8) {
+        if (M % 256 != 0) { cva_set_error("fp8 engine: batch * tokens (%zu) must be a multiple of 256", M); return CV_ERR_UNSUPPORTED; }
+        const size_t hid8 = (size_t)D * c.mlp_ratio;
+        CVA_TRY(A(&h->xn8, M * D));
+        CVA_TRY(A(&h->xn_sca, M * D / 32, true));
+        CVA_TRY(A(&h->xn_scw, M * D / 32, true));
+        CVA_TRY(A(&h->hidden8, M * hid8));
+        CVA_TRY(A(&h->hidden_sc, M * hid8 / 32, true));
+        h->hidden = nullptr;
+    } else {
+        CVA_TRY(A(&h->hidden, M * D * c.mlp_ratio * es));
+    }
     for (int j = 0; j < 4; ++j) CVA_TRY(A(&h->z[j], (size_t)B * g.P * D * es));
     CVA_TRY(A(&h->img8, (size_t)B * H * W * h->dec0[0].Ctot * es));
     const size_t hw = (size_t)H * W;
@@ -830,8 +950,8 @@ static int forward_checked(cv_handle* h, const float* x_dev, const InputU8* u8, 
             if (!h->blocks[i].tab_h || !h->blocks[i].tab_w) { cva_set_error("derived rel-pos tables of block %d not set", i); return CV_ERR_STATE; }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     g_prof = &h->prof;
-    const int rc = h->cfg.compute_dtype == CV_DTYPE_F16 ? forward_impl<half_t>(h, x_dev, u8, B, out, st)
-                                                         : forward_impl<float>(h, x_dev, u8, B, out, st);
+    const int rc = !is_f32(h->cfg.compute_dtype) ? forward_impl<half_t>(h, x_dev, u8, B, out, st)
+                                                   : forward_impl<float>(h, x_dev, u8, B, out, st);
     g_prof = nullptr;
     return rc;
 }
@@ -889,7 +1009,7 @@ extern "C" int cv_debug_read(cv_handle* h, const char* name, float* host_dst, si
     if (n_out) *n_out = n;
     if (n > capacity) { cva_set_error("capacity too small: need %zu", n); return CV_ERR_INVALID; }
     CVA_CHECK_HIP(hipDeviceSynchronize());
-    if (!is_T || c.compute_dtype == CV_DTYPE_F32) {
+    if (!is_T || is_f32(c.compute_dtype)) {
         CVA_CHECK_HIP(hipMemcpy(host_dst, src, n * 4, hipMemcpyDeviceToHost));
     } else {
         float* tmp;
@@ -979,6 +1099,62 @@ extern "C" int cv_op_attention(int dtype, const void* x, const void* Wqkv, const
     int rc = dtype == CV_DTYPE_F16
                  ? run_attention_layer<half_t>(x, w, tab_h, tab_w, window, Q, K, Vt, relh, relw, out, B, gh, gw, has_cls, heads, D, win, st)
                  : run_attention_layer<float>(x, w, tab_h, tab_w, window, Q, K, Vt, relh, relw, out, B, gh, gw, has_cls, heads, D, win, st);
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) { cva_set_error("attention: stream sync failed: %s", hipGetErrorString(hipGetLastError())); rc = CV_ERR_HIP; }
+    free_pool(pool);
+    return rc;
+}
+
+// ---- fp8 engine, single operators ----------------------------------------------------------------
+extern "C" int cv_mx8_quantize_host(const float* x, int rows, int K, int layout, uint8_t* data, uint8_t* scales) {
+    if (!x || !data || !scales || rows <= 0 || K <= 0 || K % 32 || layout < 0 || layout > 2) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    if (layout != 2 && (rows % 256 || K % 128)) { cva_set_error("tiled scale layouts need rows %% 256 == 0 and K %% 128 == 0"); return CV_ERR_INVALID; }
+    mx8_quantize(x, rows, K, data, scales, [&](int r, int k) {
+        return layout == 2 ? (size_t)r * (K / 32) + k / 32 : (size_t)mx8_scale_index(r, k, K, layout == 1); });
+    return CV_OK;
+}
+
+extern "C" int cv_op_linear_mx8(const void* A8, const void* a_scale_a, const void* a_scale_w, const void* W8, const void* w_scale,
+                                const float* bias, const float* residual, void* out, int out_kind, void* out_scale, int M, int N,
+                                int K, int act, void* stream) {
+    if (!A8 || !a_scale_a || !W8 || !w_scale || !out || out_kind < 0 || out_kind > 2) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    LinearW w; w.W8 = const_cast<void*>(W8); w.S8 = const_cast<void*>(w_scale); w.bias = const_cast<float*>(bias); w.N = N; w.K = K;
+    (void)a_scale_w;
+    return run_linear_mx8(A8, a_scale_a, K, w, residual, N, out, N, out_kind == 1, out_kind == 2 ? OUT_MX8 : OUT_LINEAR, out_scale,
+                          M, act, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int cv_op_layernorm_mx8(float* x_io, const void* delta_f16, const float* gamma, const float* beta, void* out8,
+                                   void* scale_a, void* scale_w, int M, int C, float eps, void* stream) {
+    if (!x_io || !gamma || !beta || !out8 || !scale_a) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    const int rc = launch_layernorm_mx8(x_io, C, delta_f16, gamma, beta, out8, scale_a, scale_w, M, C, eps, reinterpret_cast<hipStream_t>(stream));
+    if (rc) { cva_set_error("layernorm_mx8 launch failed (%d)", rc); return rc == (int)hipErrorInvalidValue ? CV_ERR_INVALID : CV_ERR_HIP; }
+    return CV_OK;
+}
+
+// One attention layer's qkv projection on MX-fp8 rows (cv_op_layernorm_mx8 output) + attention, as cv_op_attention.
+extern "C" int cv_op_attention_mx8(const void* x8, const void* scale_a, const void* scale_w, const void* Wqkv8, const void* wqkv_scale,
+                                   const float* bqkv, const float* tab_h, const float* tab_w, void* out, int B, int gh, int gw,
+                                   int heads, int D, int win, void* stream) {
+    if (!x8 || !scale_a || !scale_w || !Wqkv8 || !wqkv_scale || !out || D % heads) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    const int hd = D / heads, P = gh * gw, ntok = P;
+    const bool window = win > 0;
+    const int nwy = window ? (gh + win - 1) / win : 0, nwx = window ? (gw + win - 1) / win : 0;
+    const int L = window ? win * win : ntok, Lp = round_up(L, 64);
+    const size_t S = window ? (size_t)B * nwy * nwx : (size_t)B;
+    const int KH = window ? win : gh, KW = window ? win : gw;
+    std::vector<void*> pool;
+    void *Q, *K, *Vt; float *relh = nullptr, *relw = nullptr;
+    CVA_TRY(dev_alloc(pool, &Q, S * heads * L * hd * 2, true));
+    CVA_TRY(dev_alloc(pool, &K, S * heads * L * hd * 2, true));
+    CVA_TRY(dev_alloc(pool, &Vt, S * heads * hd * Lp * 2, true));
+    if (tab_h) {
+        CVA_TRY(dev_alloc(pool, (void**)&relh, S * heads * L * KH * 4));
+        CVA_TRY(dev_alloc(pool, (void**)&relw, S * heads * L * KW * 4));
+    }
+    LinearW w; w.W8 = const_cast<void*>(Wqkv8); w.S8 = const_cast<void*>(wqkv_scale); w.bias = const_cast<float*>(bqkv); w.N = 3 * D; w.K = D; w.ldw = D;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = run_attention_layer<half_t>(x8, w, tab_h, tab_w, window, Q, K, Vt, relh, relw, out, B, gh, gw, 0, heads, D, win, st, false,
+                                         scale_a, scale_w);
     if (hipStreamSynchronize(st) != hipSuccess && !rc) { cva_set_error("attention: stream sync failed: %s", hipGetErrorString(hipGetLastError())); rc = CV_ERR_HIP; }
     free_pool(pool);
     return rc;

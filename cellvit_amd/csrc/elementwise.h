@@ -14,6 +14,12 @@ int launch_layernorm(const float* in, long ld_in, const float* gamma, const floa
 int launch_layernorm_add(float* x_io, long ld, const void* delta, const float* gamma, const float* beta, void* out,
                          int M, int C, float eps, hipStream_t stream);
 
+// fp8 engine: LayerNorm whose result is the OCP MX-fp8 A operand of the next linear layer: out8 [M, C] e4m3 bytes + E8M0
+// block scales in the fragment order of gemm8.hip (sc_a: A-side image, sc_w: W-side image or null).  delta_f16 != null:
+// x_io += delta first (written back), as launch_layernorm_add.  M % 256 == 0, C % 128 == 0.
+int launch_layernorm_mx8(float* x_io, long ld, const void* delta_f16, const float* gamma, const float* beta, void* out8, void* sc_a,
+                         void* sc_w, int M, int C, float eps, hipStream_t stream);
+
 // x fp32 NCHW [B,3,H,W] -> patch matrix [B*(H/16)*(W/16), 768] of T, k = c*256 + ky*16 + kx
 // (the flattening of Conv2d(3, D, 16, 16).weight — vits_histo.py:273-280, image_encoder.py:418-426).
 // Raw-tile input (F0 fused): x uint8 NHWC [B,H,W,3]; every consumer of the image evaluates the reference's inference

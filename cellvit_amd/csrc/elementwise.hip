@@ -1,5 +1,6 @@
 // Bandwidth-bound helper kernels — see elementwise.h.
 #include "elementwise.h"
+#include "gemm.h"
 
 #include <stdlib.h>
 
@@ -123,6 +124,84 @@ __global__ __launch_bounds__(256, MAXV <= 5 ? 8 : 4) void layernorm_add_kernel(f
 #pragma unroll
             for (int j = 0; j < 4; ++j) h[j] = (half_t)((v[i][j] - mean) * rstd * g[j] + b[j]);
             __builtin_nontemporal_store(h, reinterpret_cast<half4_t*>(out + (long)row * C + idx * 4));
+        }
+    }
+}
+
+// LayerNorm with an OCP MX-fp8 result (fp8 engine): the normalised row leaves as e4m3 bytes + one E8M0 scale per 32
+// columns — the A operand of the next linear layer (gemm8.hip, F8).  A 32-column block is the 4 values of 8 consecutive
+// lanes.  HAS_DELTA: the residual add of the fp16 engine's layernorm_add_kernel (x += delta, written back) rides along.
+// Scale bytes are stored in the consumer's fragment order (mx8_scale_index): A-side image always, W-side image as well
+// when sc_w != null (the qkv projection runs its V tiles with the operands exchanged).
+template <int MAXV, bool HAS_DELTA>
+__global__ __launch_bounds__(256, MAXV <= 5 ? 8 : 4) void layernorm_mx8_kernel(float* x_io, long ld, const half_t* delta,
+                                                                                const float* __restrict__ gamma,
+                                                                                const float* __restrict__ beta,
+                                                                                unsigned char* __restrict__ out8,
+                                                                                unsigned char* __restrict__ sc_a,
+                                                                                unsigned char* __restrict__ sc_w, int M, int C,
+                                                                                float eps) {
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float* x = x_io + (long)row * ld;
+    const int nv = C >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < nv) {
+            v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + idx * 4));
+            if (HAS_DELTA) {
+                const half4_t d = __builtin_nontemporal_load(reinterpret_cast<const half4_t*>(delta + (long)row * C + idx * 4));
+                v[i] = v[i] + f32x4{(float)d[0], (float)d[1], (float)d[2], (float)d[3]};
+                __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4*>(x + idx * 4));
+            }
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else v[i] = (f32x4)(0.f);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < nv) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = i * 64 + lane;          // nv is a multiple of 8 (C % 32 == 0): a block's 8 lanes are all in or all out
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
+        if (idx < nv) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + idx * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + idx * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+        }
+        float amax = fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3])));
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, __shfl_xor(amax, 4));
+        if (idx < nv) {
+            const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
+            int sbyte = ex - 8; sbyte = sbyte < 0 ? 0 : sbyte;                  // E8M0: 2^(sbyte - 127) = 2^(floor(log2 amax) - 8)
+            const float inv = __uint_as_float((unsigned)(254 - sbyte) << 23);
+            int pk = 0;
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(y[0] * inv, -448.f, 448.f),
+                                                 __builtin_amdgcn_fmed3f(y[1] * inv, -448.f, 448.f), pk, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(y[2] * inv, -448.f, 448.f),
+                                                 __builtin_amdgcn_fmed3f(y[3] * inv, -448.f, 448.f), pk, true);
+            *reinterpret_cast<int*>(out8 + (long)row * C + idx * 4) = pk;
+            if ((lane & 7) == 0) {
+                const int k = idx * 4;
+                sc_a[mx8_scale_index(row, k, C, false)] = (unsigned char)sbyte;
+                if (sc_w) sc_w[mx8_scale_index(row, k, C, true)] = (unsigned char)sbyte;
+            }
         }
     }
 }
@@ -368,6 +447,19 @@ static U8Norm make_norm(const InputU8* u8) {
     U8Norm nm{};
     if (u8) for (int c = 0; c < 3; ++c) { nm.mean[c] = u8->mean[c]; nm.stdv[c] = u8->stdv[c]; }
     return nm;
+}
+
+int launch_layernorm_mx8(float* x_io, long ld, const void* delta_f16, const float* gamma, const float* beta, void* out8, void* sc_a,
+                         void* sc_w, int M, int C, float eps, hipStream_t stream) {
+    if (C % 128 != 0 || C > 64 * 4 * 8 || M % 256 != 0) return (int)hipErrorInvalidValue;
+    const dim3 grid((M + 3) / 4), block(256);
+    const half_t* d = reinterpret_cast<const half_t*>(delta_f16);
+    unsigned char *o = reinterpret_cast<unsigned char*>(out8), *a = reinterpret_cast<unsigned char*>(sc_a), *w = reinterpret_cast<unsigned char*>(sc_w);
+#define CVA_LN8(MV) do { if (d) hipLaunchKernelGGL((layernorm_mx8_kernel<MV, true>), grid, block, 0, stream, x_io, ld, d, gamma, beta, o, a, w, M, C, eps); \
+                         else hipLaunchKernelGGL((layernorm_mx8_kernel<MV, false>), grid, block, 0, stream, x_io, ld, d, gamma, beta, o, a, w, M, C, eps); } while (0)
+    if (C <= 64 * 4 * 2) CVA_LN8(2); else if (C <= 64 * 4 * 5) CVA_LN8(5); else CVA_LN8(8);
+#undef CVA_LN8
+    return (int)hipGetLastError();
 }
 
 template <typename T>

@@ -12,7 +12,27 @@ namespace cva {
 
 enum : int { A_LINEAR = 0, A_CONV3 = 1 };
 enum : int { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
-enum : int { OUT_LINEAR = 0, OUT_QKV = 1, OUT_CONVT = 2 };
+enum : int { OUT_LINEAR = 0, OUT_QKV = 1, OUT_CONVT = 2, OUT_MX8 = 3 };   // OUT_MX8: MX-fp8 rows + block scales (fp8 engine)
+
+// ---- OCP MX-fp8 operands of the fp8 engine (gemm8.hip, F8 = 1) --------------------------------------------------------
+// Elements: e4m3 (max 448), one E8M0 scale (2^(byte - 127)) per 32 consecutive K elements of a row.  Data [rows, K] bytes,
+// row-major.  Scales live in 1-KiB blocks, one per (256-row tile, 128-element K tile) = 256 rows x 4 K blocks, at
+// ((row / 256) * (K / 128) + k / 128) * 1024 + off(row % 256, (k % 128) / 32), where off is the order in which the MFMA
+// lanes of gemm8_kernel want them (one ds_read_b32 = the scales of the four fragments of a sub-tile for lane (g, li)):
+//   A side (operand in the "A" LDS tile, natural row order): fragment row = wr*128 + mh*64 + mi*16 + li
+//   W side (operand in the "W" LDS tile, rows permuted for the transposed epilogue): source row = wc*64 + q*16 + nj*4 + r,
+//          read by lane li = q*4 + r of fragment nj
+__host__ __device__ inline int mx8_scale_off_a(int rr, int g) {
+    return (((((rr >> 7) * 2 + ((rr >> 6) & 1)) * 4 + g) * 16 + (rr & 15)) << 2) | ((rr >> 4) & 3);
+}
+__host__ __device__ inline int mx8_scale_off_w(int rr, int g) {
+    return (((((rr >> 6) * 4 + g) * 16) + (((rr >> 4) & 3) * 4 + (rr & 3))) << 2) | ((rr >> 2) & 3);
+}
+__host__ __device__ inline long mx8_scale_index(long row, int k, int K, bool w_side) {
+    const long blk = (row >> 8) * (K >> 7) + (k >> 7);
+    const int rr = (int)(row & 255), g = (k & 127) >> 5;
+    return blk * 1024 + (w_side ? mx8_scale_off_w(rr, g) : mx8_scale_off_a(rr, g));
+}
 
 struct GemmParams {
     // ---- problem ----
@@ -45,6 +65,11 @@ struct GemmParams {
     // conv3x3 halo kernel only: fused 1x1 output head (cellvit.py:309-315) on the ReLU output; the 64-channel
     // activation itself is then not written (out may be null).  logits fp32 NCHW [B, nout, H, W], argmax u8 [B, H, W].
     const float* head_W; const float* head_b; float* head_logits; uint8_t* head_argmax; int head_nout, head_narg;
+    // fp8 engine (launch_gemm8_f8): A / W are e4m3 bytes, lda / ldw in elements (= bytes)
+    const void* a_scale;             // activation scales, A-side layout (mx8_scale_index(.., false))
+    const void* a_scale_w;           // the same scales in the W-side layout (needed by the swapped V tiles of OUT_QKV), or null
+    const void* w_scale;             // weight scales; tiles that run swapped (qkv rows >= 2D) are packed in the A-side layout
+    void* out_scale;                 // OUT_MX8: scales of the fp8 output (A-side layout for a consumer GEMM with K = N)
     int epi_vec;                     // 1: LDS-staged 16-byte epilogue stores (set by launch_gemm)
     int dbg;                         // experiment switches (CVA_GEMM_DBG): 1 no staging, 2 no LDS reads, 4 no L2 prefetch
 };
@@ -54,6 +79,10 @@ template <typename T> int launch_gemm(const GemmParams& p, int a_mode, hipStream
 // gemm8.hip: 256x256x64 8-phase fp16 kernel (A_LINEAR only); launch_gemm routes to it when the shape qualifies.
 bool gemm8_supported(const GemmParams& p, int a_mode, size_t elem_size);
 int launch_gemm8(const GemmParams& p, hipStream_t stream);
+// fp8 engine: the same kernel on MX-fp8 operands; out_mode OUT_LINEAR (fp32 / fp16 out, optional residual), OUT_QKV or
+// OUT_MX8.  Returns hipErrorInvalidValue when the shape does not qualify (there is no fallback kernel for fp8 operands).
+bool gemm8_f8_supported(const GemmParams& p);
+int launch_gemm8_f8(const GemmParams& p, hipStream_t stream);
 
 // >= 256 B of zeros in device memory (DMA source for out-of-range pieces)
 void* gemm_zero_page();

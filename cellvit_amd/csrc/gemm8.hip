@@ -35,6 +35,18 @@
 //  waits — LDS-DMA loads and VGPR loads do not retire in order with respect to each other.  Giving the DMA to one
 //  wave group and L2-prefetch touches to the other is correct but 4-8 % SLOWER than no prefetch: the stalls at the
 //  counted waits are not HBM misses that a touch could turn into L2 hits.)
+//
+// F8 = 1: the same schedule on OCP MX-fp8 operands (e4m3 elements, one E8M0 scale per 32 K elements: BASELINE.json
+// configs[4]).  A tile row is still 128 bytes = 128 K elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 step (8 passes, twice
+// the FLOPs per cycle of the fp16 instruction), so the LDS image, the DMA, the number of fragment reads and the phase
+// table carry over unchanged; what differs:
+//   * a lane's operand is 32 CONTIGUOUS bytes of its row (k block g = lane >> 4: pieces 2g, 2g + 1) so that it is exactly one
+//     scale block; the source-side swizzle is piece ^ f((row >> 1) & 7), f(b2 b1 b0) = (b2, b0, b2 ^ b1), which keeps the four
+//     16-lane groups of both ds_read_b128 conflict free for this piece assignment;
+//   * the scales of a K tile (256 rows x 4 blocks = 1 KiB per operand) ride in with the tile's A stage as ONE extra
+//     global_load_lds_dword per wave and are stored in global memory already in the order the fragment reads want them:
+//     ONE ds_read_b32 hands a lane the scales of the four fragments of a sub-tile, selected per MFMA by op_sel
+//     (layouts: mx8_scale_off_a / mx8_scale_off_w in gemm.h, written by the producers / the weight packer).
 #include "gemm.h"
 #include "gemm_epilogue.h"
 
@@ -50,7 +62,8 @@ constexpr int G8_WOFF = 2 * G8_TILE;        // LDS layout: [E.A][O.A][E.W][O.W] 
 constexpr int G8_BIAS = 4 * G8_TILE;       // two 1-KiB bias slots (256 floats each, alternating per output tile)
 constexpr int G8_LUT = 4 * G8_TILE + 2048;  // GELU: Phi(x) at x = -8 + i/128, i = 0 .. 2048 (fp32), filled once per workgroup
 constexpr int G8_LUTN = 2048;
-constexpr int G8_LDS = G8_LUT + (G8_LUTN + 1) * 4 + 12;
+constexpr int G8_SC = G8_LUT + (G8_LUTN + 1) * 4 + 12;      // F8: scale images, [E | O] x [A-side 1 KiB | W-side 1 KiB]
+constexpr int G8_LDS = G8_SC + 4096;
 
 #define G8_BAR()                                   \
     do {                                           \
@@ -75,6 +88,42 @@ constexpr int G8_LDS = G8_LUT + (G8_LUTN + 1) * 4 + 12;
                               : __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][ks], b[nj][ks],              \
                                                                        acc[(MH) * 4 + mi][(NH) * 2 + nj], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                    \
+    } while (0)
+
+// F8: the 8 MFMAs of quadrant (MH, NH) of one K tile: C^T[nj][mi] += W[nj] . A[mi]^T with the block scales of both operands.
+// a / b: per-fragment 32-byte operands (8 VGPRs, must be one register tuple — which is why the fp8 fragments are ordinary
+// compiler-visible LDS loads and not inline-asm reads: two asm-defined 16-byte halves would have to be copied together);
+// sa / sb: one dword holding the four fragment scales, selected by op_sel.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+#define G8_MM8(a, b, sa, sb, MH, NH, mi, nj)                                                                     \
+    acc[(MH) * 4 + (mi)][(NH) * 2 + (nj)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                    \
+        b[nj], a[mi], acc[(MH) * 4 + (mi)][(NH) * 2 + (nj)], 0, 0, (NH) * 2 + (nj), sb, (mi), sa)
+// (the two empty asm statements pin the MFMAs between this phase's barriers: register-only instructions are otherwise free
+//  to move across "memory"-clobbering asm and sched_barrier, and the compiler was seen to collect a whole iteration's
+//  MFMAs behind all of its loads — every fragment live at once, 240 spilled VGPRs)
+#define G8_MMQ8(a, b, sa, sb, MH, NH)                                                                            \
+    do {                                                                                                         \
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(sa), "+v"(sb)); \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        G8_MM8(a, b, sa, sb, MH, NH, 0, 0); G8_MM8(a, b, sa, sb, MH, NH, 0, 1);                                  \
+        G8_MM8(a, b, sa, sb, MH, NH, 1, 0); G8_MM8(a, b, sa, sb, MH, NH, 1, 1);                                  \
+        G8_MM8(a, b, sa, sb, MH, NH, 2, 0); G8_MM8(a, b, sa, sb, MH, NH, 2, 1);                                  \
+        G8_MM8(a, b, sa, sb, MH, NH, 3, 0); G8_MM8(a, b, sa, sb, MH, NH, 3, 1);                                  \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+        asm volatile("" : "+v"(acc[(MH) * 4 + 0][(NH) * 2]), "+v"(acc[(MH) * 4 + 0][(NH) * 2 + 1]),               \
+                          "+v"(acc[(MH) * 4 + 1][(NH) * 2]), "+v"(acc[(MH) * 4 + 1][(NH) * 2 + 1]),               \
+                          "+v"(acc[(MH) * 4 + 2][(NH) * 2]), "+v"(acc[(MH) * 4 + 2][(NH) * 2 + 1]),               \
+                          "+v"(acc[(MH) * 4 + 3][(NH) * 2]), "+v"(acc[(MH) * 4 + 3][(NH) * 2 + 1]));              \
+    } while (0)
+// The fp8 path's barrier is inline asm: the compiler then does not treat it as a point where its own (tracked) LDS loads
+// must have returned, and places a counted s_waitcnt lgkmcnt(n) in front of the first MFMA that consumes a fragment instead
+// — the next phase's reads stay in flight across the barrier, as the hand-counted waits of the fp16 path arrange.
+#define G8_BAR8()                                  \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        asm volatile("s_barrier" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);         \
     } while (0)
 
 // Pin a wave-uniform pointer into SGPRs (opaque to the optimiser): the DMA then uses the
@@ -192,6 +241,31 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
                     *reinterpret_cast<half8_t*>(o + q * 8) = w;
                 }
             }
+        } else if (OMODE == OUT_MX8) {
+            // MX-fp8 output (the hidden activation of the MLP, consumed as the A operand of fc2): a 32-column scale block is
+            // this lane's 16 values + those of lane ^ 16 (g ^ 1).  OCP MX: shared exponent = floor(log2(amax)) - 8 (e4m3 emax),
+            // elements = v * 2^-shared, saturated to +-448, round to nearest even (v_cvt_pk_fp8_f32).
+            float amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(v[e]));
+            amax = fmaxf(amax, __shfl_xor(amax, 16));
+            const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);          // biased exponent of amax (0 for zero / denormal)
+            int sbyte = ex - 8; sbyte = sbyte < 0 ? 0 : sbyte;                  // E8M0 byte = shared exponent + 127
+            const float inv = __uint_as_float((unsigned)(254 - sbyte) << 23);   // 2^-(sbyte - 127)
+            i32x4_t w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int pk = 0;
+                const float x0 = __builtin_amdgcn_fmed3f(v[q * 4 + 0] * inv, -448.f, 448.f), x1 = __builtin_amdgcn_fmed3f(v[q * 4 + 1] * inv, -448.f, 448.f);
+                const float x2 = __builtin_amdgcn_fmed3f(v[q * 4 + 2] * inv, -448.f, 448.f), x3 = __builtin_amdgcn_fmed3f(v[q * 4 + 3] * inv, -448.f, 448.f);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, pk, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, pk, true);
+                w[q] = pk;
+            }
+            unsigned char* o8 = reinterpret_cast<unsigned char*>(p.out) + (long)m * p.ldc + n;
+            *reinterpret_cast<i32x4_t*>(o8) = w;
+            if (!(g & 1))
+                reinterpret_cast<unsigned char*>(p.out_scale)[mx8_scale_index(m, n, p.N, false)] = (unsigned char)sbyte;
         } else if (OMODE == OUT_CONVT) {
             // ConvTranspose2d k2 s2: row m = input pixel (b, y, x), column n = (dy*2 + dx) * Cout + co; the lane's 16 columns
             // are 16 consecutive co of one (dy, dx) (Cout % 16 == 0): one 32-byte run of output pixel (2y + dy, 2x + dx).
@@ -315,15 +389,24 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
     }
 }
 
-template <int OMODE, int TRANS, int ABL>
+// swizzle of the 16-byte piece index inside a 128-byte LDS row, as a function of h = (row >> 1) & 7 (applied on the DMA
+// source side and in the fragment reads): fp16 h itself; fp8 f(b2 b1 b0) = (b2, b0, b2 ^ b1) (see the file header)
+template <int F8> __device__ __forceinline__ int g8_swz(int h) {
+    return F8 ? ((h & 4) | ((h & 1) << 1) | (((h >> 2) ^ (h >> 1)) & 1)) : h;
+}
+
+template <int OMODE, int TRANS, int ABL, int F8>
 __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    static_assert(!F8 || (TRANS == 1 && ABL == 0), "the fp8 variant exists for the direct (transposed) epilogues only");
+    constexpr int ESZ = F8 ? 1 : 2;                 // bytes per operand element; a tile row is 128 bytes either way
+    constexpr int KTE = 128 / ESZ;                  // K elements per tile
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int tiles_n = p.N / G8_BN, tiles_m = p.M / G8_BM, ntiles = tiles_m * tiles_n;
-    const int nk = p.K / G8_BK;                     // even, >= 2 (host)
+    const int nk = p.K / KTE;                       // even, >= 2 (host)
 
     // ---- per-tile state.  (m0, n0, swap) of the tile being computed / stored; the DMA row offsets and bases below
     // always describe the tile whose DMA is issued NEXT (they are advanced to tile t+1 before tile t's epilogue).
@@ -331,11 +414,15 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     auto a_bytes = [&](int m) {       // byte offset of activation row m
         long r = m;
         if (p.a_rpi > 0) r = (long)m + (long)(m / p.a_rpi) * p.a_extra + p.a_off;
-        return (unsigned)(r * (long)p.lda * 2);
+        return (unsigned)(r * (long)p.lda * ESZ);
     };
     unsigned a_voff[4], w_voff[4];
     const unsigned char* Ab;
     const unsigned char* Wb;
+    // F8: this wave's 256-byte share of the tile's scale block pair.  Waves 0-3 fetch the A-side block (scales of the
+    // operand that sits in the "A" LDS tile), waves 4-7 the W-side block; block (row tile, K tile) is 1 KiB.
+    const unsigned char* Sb = nullptr;
+    const unsigned sc_voff = (unsigned)((wave & 3) * 256 + lane * 4);
     // K direction of the tile whose DMA is issued next: a workgroup's consecutive tiles share their A panel (same tile
     // row, next columns), so every other tile walks K BACKWARDS — the panel's most recently streamed K slices are
     // still in L2 when the next tile starts from that end.
@@ -351,20 +438,29 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave * 32 + i * 8 + lrow;
-            const int lp = lpc ^ ((row >> 1) & 7);
+            const int lp = lpc ^ g8_swz<F8>((row >> 1) & 7);
             // TRANS: LDS row wc*64 + j*16 + g*4 + r of the "W" tile holds source row wc*64 + g*16 + j*4 + r, so that a
             // lane's 16 accumulator values per output row are 16 consecutive columns (see epilogue8_direct)
             const int prow = TRANS == 1 ? ((row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3)) : row;
             if (!swap) {
                 a_voff[i] = a_bytes(m0 + row) + lp * 16;
-                w_voff[i] = (unsigned)((long)(n0 + prow) * p.ldw * 2) + lp * 16;
+                w_voff[i] = (unsigned)((long)(n0 + prow) * p.ldw * ESZ) + lp * 16;
             } else {
-                a_voff[i] = (unsigned)((long)(n0 + row) * p.ldw * 2) + lp * 16;
+                a_voff[i] = (unsigned)((long)(n0 + row) * p.ldw * ESZ) + lp * 16;
                 w_voff[i] = a_bytes(m0 + prow) + lp * 16;
             }
         }
         Ab = reinterpret_cast<const unsigned char*>(swap ? p.W : p.A);
         Wb = reinterpret_cast<const unsigned char*>(swap ? p.A : p.W);
+        if (F8) {
+            // scale images: activations  A-side layout p.a_scale (p.a_scale_w = W-side layout, for the swapped V tiles);
+            //               weights      p.w_scale, packed per 256-row tile in the layout of the side the tile runs on
+            const bool a_side = wave < 4;
+            const unsigned char* act = reinterpret_cast<const unsigned char*>(a_side == !swap ? p.a_scale : p.a_scale_w);
+            const unsigned char* wgt = reinterpret_cast<const unsigned char*>(p.w_scale);
+            const bool take_act = a_side == !swap;          // A side holds activations unless swapped
+            Sb = take_act ? act + (long)(m0 / G8_BM) * nk * 1024 : wgt + (long)(n0 / G8_BN) * nk * 1024;
+        }
     };
 
     // Direct-to-LDS DMA, written as inline asm to pin the `v_off, s[base:base+1]` addressing form (the builtin lets the
@@ -374,7 +470,15 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 #define G8_DMA(voff, base, ldsaddr)                                                                         \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), \
                  "s"(ldsaddr) : "memory")
+#define G8_DMA4(voff, base, ldsaddr)                                                                        \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), \
+                 "s"(ldsaddr) : "memory")
     auto stage_a = [&](int buf, int kt) {
+        if (F8) {      // the K tile's scale blocks first (oldest load of the stage: every counted wait that covers the tile covers them)
+            const unsigned char* sbase = uniform_ptr(Sb + (long)(kstart + kt * kstep) * 1024);
+            const unsigned sdst = __builtin_amdgcn_readfirstlane(lds0 + G8_SC + buf * 2048 + wave * 256);
+            G8_DMA4(sc_voff, sbase, sdst);
+        }
         const unsigned char* base = uniform_ptr(Ab + (long)(kstart + kt * kstep) * (G8_BK * 2));
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G8_TILE + wave * 4096);
 #pragma unroll
@@ -388,9 +492,10 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     };
 
     // ---- fragment read offsets: row r (r & 15 == lane & 15), logical piece ks*4 + g -> byte r*128 + ((lp ^ ((r>>1)&7)) << 4)
+    // (F8: logical pieces 2g and 2g + 1 -> byte li*128 + (((2g) ^ f) << 4) and that ^ 16)
     const int g = lane >> 4, li = lane & 15;
-    const int off0 = li * 128 + ((g ^ ((li >> 1) & 7)) << 4);
-    const int d1 = 64 - 2 * (off0 & 64);                          // offset of the second k-step piece: off ^ 64
+    const int off0 = li * 128 + (((F8 ? 2 * g : g) ^ g8_swz<F8>((li >> 1) & 7)) << 4);
+    const int d1 = F8 ? 16 - 2 * (off0 & 16) : 64 - 2 * (off0 & 64);   // offset of the second piece: off ^ 64 (fp16: k step 1), off ^ 16 (fp8)
     const unsigned a_ad0 = lds0 + (wr * 128) * 128 + off0, a_ad1 = a_ad0 + d1;              // + buf*32K + mh*8K + mi*2K
     const unsigned w_ad0 = lds0 + G8_WOFF + (wc * 64) * 128 + off0, w_ad1 = w_ad0 + d1;     // + buf*32K + nh*4K + nj*2K
 
@@ -423,6 +528,28 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
                    "+v"(a[3][0]), "+v"(a[3][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1])       \
                  :: "memory")
 
+    // ---- F8: fragments (32 bytes = pieces 2g, 2g+1 of a row) and scale dwords as compiler-visible LDS loads
+    typedef const __attribute__((address_space(3))) unsigned char* lds_cp;
+    const lds_cp lds_base = (lds_cp)(__attribute__((address_space(3))) void*)smem8;
+    const lds_cp fa0 = lds_base + (a_ad0 - lds0), fw0 = lds_base + (w_ad0 - lds0);      // second half at + d1
+    const lds_cp sa_p = lds_base + G8_SC + (wr * 2) * 256 + lane * 4;                    // + buf*2048 + mh*256
+    const lds_cp sw_p = lds_base + G8_SC + 1024 + wc * 256 + lane * 4;                   // + buf*2048
+    i32x8_t F0[4], F1[4], FX[2], FY[2];
+    int sA0 = 0, sA1 = 0, sWE = 0, sWO = 0;
+    auto ld32 = [&](lds_cp q) -> i32x8_t {
+        const i32x4_t lo = *reinterpret_cast<const __attribute__((address_space(3))) i32x4_t*>(q);
+        const i32x4_t hi = *reinterpret_cast<const __attribute__((address_space(3))) i32x4_t*>(q + d1);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+#define G8F_RD_A(f, sc, BUF, MH)                                                                               \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) f[mi_] = ld32(fa0 + (BUF) * G8_TILE + (MH) * 8192 + mi_ * 2048); \
+        sc = *reinterpret_cast<const __attribute__((address_space(3))) int*>(sa_p + (BUF) * 2048 + (MH) * 256); \
+    } while (0)
+#define G8F_RD_W(f, BUF, NH)                                                                                   \
+    do { _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) f[nj_] = ld32(fw0 + (BUF) * G8_TILE + (NH) * 4096 + nj_ * 2048); } while (0)
+#define G8F_RD_SW(sc, BUF) sc = *reinterpret_cast<const __attribute__((address_space(3))) int*>(sw_p + (BUF) * 2048)
+
     constexpr bool no_dma = ABL & 1, no_rd = ABL & 2, no_epi = ABL & 4;   // experiment instantiations (CVA_GEMM_DBG), ABL = 0 in production
 
     // E <- tile 0, O <- tile 1 of the K loop (16 DMA loads per lane); wave 0 first fetches the tile's 256 bias values
@@ -439,12 +566,12 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         stage_a(0, 0);
         stage_w(0, 0);
         stage_w(1, 1);
-        stage_a(1, 1);
+        if (!F8) stage_a(1, 1);      // (fp8 schedule: O.A is staged in phase 1 of every iteration, the first included)
     };
 
     // ---- persistent loop over output tiles: the DMA of tile t+1's first two K tiles is issued BEFORE tile t's
     // epilogue, so its latency (and the epilogue's store drain) overlap instead of adding up
-    if (TRANS && OMODE == OUT_LINEAR && p.act == ACT_GELU) {     // (read only in epilogues: many barriers later)
+    if (TRANS && (OMODE == OUT_LINEAR || OMODE == OUT_MX8) && p.act == ACT_GELU) {     // (read only in epilogues: many barriers later)
         float* lut = reinterpret_cast<float*>(smem8 + G8_LUT);
         for (int i = threadIdx.x; i <= G8_LUTN; i += G8_NT) lut[i] = 0.5f * (1.0f + erff((-8.0f + (float)i * (1.0f / 128.f)) * 0.70710678118654752f));
     }
@@ -460,6 +587,56 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
 
+        if constexpr (F8) {
+            // fp8 schedule: a fragment set is read at the START of the phase that first consumes it (three sets = 64 VGPRs
+            // live instead of four: the 32-byte operands must be register tuples, so the reads are compiler-visible loads and
+            // the budget is the allocator's); the exposed LDS latency hides behind the other wave group's MFMAs (the groups
+            // run one barrier apart).  Reads one phase later -> every re-stage one phase later than in the fp16 table:
+            //   phase  quadrant  reads at phase start                         DMA issued              counted wait
+            //   1      (0,0)     A0 <- E.A s0 (+scales), X <- E.W s0 (+sc)    O.A <- tile kt+1
+            //   2      (0,1)     Y  <- E.W s1
+            //   3      (1,1)     A1 <- E.A s1 (+scales)
+            //   4      (1,0)     -                                            E.W <- tile kt+2        vmcnt(4): O complete
+            //   5      (0,0)     A0 <- O.A s0 (+scales), Y <- O.W s0 (+sc)    E.A <- tile kt+2
+            //   6      (0,1)     X  <- O.W s1
+            //   7      (1,1)     A1 <- O.A s1 (+scales)
+            //   8      (1,0)     -                                            O.W <- tile kt+3        vmcnt(4): E complete
+            //   (the prologue of an output tile stages E.A, E.W and O.W: phase 1 is the same in every iteration)
+            // WAR (re-stage >= 2 phases after the last read): E.W 2 -> 4, E.A 3 -> 5, O.W 6 -> 8, O.A 7 -> 1'; the scale images
+            // travel with the A stages (E: last read 3 -> 5, O: 7 -> 1').  RAW (read >= 1 phase after the retiring wait): O 4 -> 5, E 8 -> 1'.
+            G8_VMCNT(4);                            // E (tile + its scale blocks) has landed; O.W may still be in flight
+            G8_BAR8();
+            if (wr == 1) G8_BAR8();                 // stagger the second wave group by one barrier
+            for (int kt = 0; kt < nk; kt += 2) {
+                const bool more = kt + 2 < nk;      // block-uniform
+                // ---- phase 1
+                G8F_RD_A(F0, sA0, 0, 0); G8F_RD_W(FX, 0, 0); G8F_RD_SW(sWE, 0);
+                stage_a(1, kt + 1);
+                G8_BAR8(); G8_MMQ8(F0, FX, sA0, sWE, 0, 0); G8_BAR8();
+                // ---- phase 2
+                G8F_RD_W(FY, 0, 1);
+                G8_BAR8(); G8_MMQ8(F0, FY, sA0, sWE, 0, 1); G8_BAR8();
+                // ---- phase 3
+                G8F_RD_A(F1, sA1, 0, 1);
+                G8_BAR8(); G8_MMQ8(F1, FY, sA1, sWE, 1, 1); G8_BAR8();
+                // ---- phase 4
+                if (more) { stage_w(0, kt + 2); G8_VMCNT(4); } else { G8_VMCNT(0); }
+                G8_BAR8(); G8_MMQ8(F1, FX, sA1, sWE, 1, 0); G8_BAR8();
+                // ---- phase 5
+                G8F_RD_A(F0, sA0, 1, 0); G8F_RD_W(FY, 1, 0); G8F_RD_SW(sWO, 1);
+                if (more) stage_a(0, kt + 2);
+                G8_BAR8(); G8_MMQ8(F0, FY, sA0, sWO, 0, 0); G8_BAR8();
+                // ---- phase 6
+                G8F_RD_W(FX, 1, 1);
+                G8_BAR8(); G8_MMQ8(F0, FX, sA0, sWO, 0, 1); G8_BAR8();
+                // ---- phase 7
+                G8F_RD_A(F1, sA1, 1, 1);
+                G8_BAR8(); G8_MMQ8(F1, FX, sA1, sWO, 1, 1); G8_BAR8();
+                // ---- phase 8
+                if (more) { stage_w(1, kt + 3); G8_VMCNT(4); }
+                G8_BAR8(); G8_MMQ8(F1, FY, sA1, sWO, 1, 0); G8_BAR8();
+            }
+        } else {
         G8_VMCNT(8);                                // E has landed (O may still be in flight); older epilogue stores have drained
         G8_BAR();
         if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }
@@ -493,6 +670,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }     // (after the last tile: a harmless read of stale data)
             if (more && !no_dma) stage_a(1, kt + 3);
             G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
+        }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (wr == 0) G8_BAR();                      // re-align the wave groups: every LDS read has retired
@@ -550,11 +728,11 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     }
 }
 
-template <int OMODE, int TRANS, int ABL>
+template <int OMODE, int TRANS, int ABL, int F8 = 0>
 int launch8(const GemmParams& p, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<OMODE, TRANS, ABL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<OMODE, TRANS, ABL, F8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr = true;
@@ -567,7 +745,7 @@ int launch8(const GemmParams& p, hipStream_t stream) {
     }
     const int tiles = (p.M / G8_BM) * (p.N / G8_BN);
     const int grid = (tiles < n_cu || (p.dbg & 32)) ? tiles : n_cu;   // persistent: one workgroup per CU walks tiles grid-stride
-    hipLaunchKernelGGL((gemm8_kernel<OMODE, TRANS, ABL>), dim3(grid), dim3(G8_NT), G8_LDS, stream, p);
+    hipLaunchKernelGGL((gemm8_kernel<OMODE, TRANS, ABL, F8>), dim3(grid), dim3(G8_NT), G8_LDS, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -582,6 +760,27 @@ bool gemm8_supported(const GemmParams& p, int a_mode, size_t elem_size) {
     if ((max_arow + 1) * (long)p.lda * 2 >= (1L << 31) || (long)p.N * p.ldw * 2 >= (1L << 31)) return false;
     if (p.out_mode == OUT_QKV && (p.D % G8_BN || p.hd % 16 || p.N != 3 * p.D || p.n_off)) return false;
     return true;
+}
+
+bool gemm8_f8_supported(const GemmParams& p) {
+    if (p.M % G8_BM || p.N % G8_BN || p.K % 256 || p.K < 256) return false;             // K tiles of 128 elements, two per iteration
+    if (((size_t)p.A & 15) || ((size_t)p.W & 15) || (p.lda % 16) || (p.ldw % 16) || p.lda < p.K || p.ldw < p.K) return false;
+    if (p.a_rpi || !p.a_scale || !p.w_scale) return false;
+    if (((size_t)p.a_scale & 3) || ((size_t)p.w_scale & 3)) return false;
+    if ((long)p.M * p.lda >= (1L << 31) || (long)p.N * p.ldw >= (1L << 31)) return false;   // 32-bit lane offsets
+    if (p.out_mode == OUT_QKV && (p.D % G8_BN || p.hd % 16 || p.N != 3 * p.D || p.n_off || !p.a_scale_w)) return false;
+    if (p.out_mode == OUT_MX8 && (!p.out || !p.out_scale || p.ldc % 16 || p.N % 128)) return false;
+    if (p.out_mode == OUT_CONVT) return false;
+    return true;
+}
+
+int launch_gemm8_f8(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.dbg = 0; p.epi_vec = 1;
+    if (!gemm8_f8_supported(p)) return (int)hipErrorInvalidValue;
+    if (p.out_mode == OUT_LINEAR) return launch8<OUT_LINEAR, 1, 0, 1>(p, stream);
+    if (p.out_mode == OUT_QKV) return launch8<OUT_QKV, 1, 0, 1>(p, stream);
+    return launch8<OUT_MX8, 1, 0, 1>(p, stream);
 }
 
 int launch_gemm8(const GemmParams& p, hipStream_t stream) {

@@ -157,7 +157,8 @@ class CellViT(nn.Module):
     Args mirror the reference constructor; the dropout arguments are accepted and ignored (they are
     identity in eval mode, the only mode of this inference path).
     ``compute_dtype``: "auto" (fp16 under ``torch.autocast``, fp32 otherwise — the reference's
-    ``mixed_precision`` switch, cell_detection.py:306-318), "fp16" or "fp32".
+    ``mixed_precision`` switch, cell_detection.py:306-318), "fp16", "fp32", or "fp8" (SAM encoders only: the fp16 engine
+    with OCP MX-fp8 qkv / fc1 / fc2 contractions on the CDNA4 block-scaled MFMA, BASELINE.json configs[4]).
     """
 
     def __init__(self, num_nuclei_classes: int, num_tissue_classes: int, embed_dim: int, input_channels: int,
@@ -232,6 +233,8 @@ class CellViT(nn.Module):
             return _lib.DTYPE_F16
         if cd in ("fp32", "f32", "float"):
             return _lib.DTYPE_F32
+        if cd in ("fp8", "f8", "mxfp8"):
+            return _lib.DTYPE_F8
         raise ValueError(f"unknown compute_dtype {cd!r}")
 
     def _engine(self, dtype: int, device: torch.device) -> _Engine:

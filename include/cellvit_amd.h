@@ -36,7 +36,12 @@ enum {
 };
 
 enum { CV_ARCH_VIT = 0, CV_ARCH_SAM = 1 };
-enum { CV_DTYPE_F16 = 0, CV_DTYPE_F32 = 1 };   /* storage type of activations/weights; MFMA accumulates fp32 */
+enum { CV_DTYPE_F16 = 0, CV_DTYPE_F32 = 1,     /* storage type of activations/weights; MFMA accumulates fp32 */
+       CV_DTYPE_F8 = 2 };                      /* the fp16 engine with OCP MX-fp8 (e4m3 + E8M0 block scales, CDNA4
+                                                  v_mfma_scale_f32_16x16x128_f8f6f4) qkv / fc1 / fc2 contractions in the
+                                                  SAM encoders; attention core, proj and the decoder stay fp16
+                                                  (BASELINE.json configs[4]).  cv_create only; the op-level entry points
+                                                  take CV_DTYPE_F16 / CV_DTYPE_F32.                                     */
 
 typedef struct cv_handle cv_handle;
 
@@ -54,7 +59,7 @@ typedef struct cv_config {
     int32_t n_global;             /* SAM: number of global-attention blocks */
     int32_t global_attn_indexes[8];
     int32_t neck_chans;           /* SAM: 256 */
-    int32_t compute_dtype;        /* CV_DTYPE_F16 (production) | CV_DTYPE_F32 (parity/debug) */
+    int32_t compute_dtype;        /* CV_DTYPE_F16 (production) | CV_DTYPE_F32 (parity/debug) | CV_DTYPE_F8 */
 } cv_config;
 
 /* Device buffers for the outputs of one forward call (fp32, contiguous, caller-allocated; NULL = skip).
@@ -146,6 +151,26 @@ int cv_op_convT2x2(int dtype, const void* src, const void* Wk, const float* bias
 int cv_op_attention(int dtype, const void* x, const void* Wqkv, const float* bqkv, const float* tab_h,
                     const float* tab_w, void* out, int B, int gh, int gw, int has_cls, int heads,
                     int D, int win, void* stream);
+
+/* ---- fp8 engine (CV_DTYPE_F8), single operators.  MX-fp8 tensor = e4m3 bytes [rows, K] row-major + one E8M0 scale byte
+ * (2^(b - 127)) per 32 K elements.  Scale bytes live in 1-KiB blocks per (256-row tile, 128-element K tile) in the order the
+ * MFMA lanes read them ("A-side" / "W-side" images, cellvit_amd/csrc/gemm.h: mx8_scale_index).                            */
+/* Host-side reference quantiser (what cv_finalize applies to the qkv / fc1 / fc2 weights): layout 0 = A-side image,
+ * 1 = W-side image, 2 = plain row-major [rows, K/32] (for checking against other implementations).                       */
+int cv_mx8_quantize_host(const float* x, int rows, int K, int layout, uint8_t* data, uint8_t* scales);
+/* out[M,N] = act(A8 . W8^T + bias) (+ residual fp32).  A scales: A-side image; W scales: W-side image.  out_kind 0: fp16,
+ * 1: fp32, 2: MX-fp8 (bytes to `out`, A-side scale image for a consumer with K = N to `out_scale`).  M, N % 256, K % 256.   */
+int cv_op_linear_mx8(const void* A8, const void* a_scale_a, const void* a_scale_w, const void* W8, const void* w_scale,
+                     const float* bias, const float* residual, void* out, int out_kind, void* out_scale, int M, int N, int K,
+                     int act, void* stream);
+/* LayerNorm(x_io (+= delta_f16 when given, written back)) -> MX-fp8 rows; scale_w (W-side image) may be NULL.                */
+int cv_op_layernorm_mx8(float* x_io, const void* delta_f16, const float* gamma, const float* beta, void* out8, void* scale_a,
+                        void* scale_w, int M, int C, float eps, void* stream);
+/* cv_op_attention with the fused qkv projection on MX-fp8 operands (x8 + both scale images from cv_op_layernorm_mx8;
+ * Wqkv8 with rows >= 2D packed in the A-side image, the others W-side); no cls token.  out: fp16 [B*gh*gw, D].              */
+int cv_op_attention_mx8(const void* x8, const void* scale_a, const void* scale_w, const void* Wqkv8, const void* wqkv_scale,
+                        const float* bqkv, const float* tab_h, const float* tab_w, void* out, int B, int gh, int gw, int heads,
+                        int D, int win, void* stream);
 
 /* argmax over dim 1 of an fp32 NCHW map -> u8 [B,H,W], first maximum (torch.argmax of cellvit.py:366-374).           */
 int cv_op_argmax_nchw(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream);

@@ -1,0 +1,235 @@
+"""GPU: the fp8 engine (BASELINE.json configs[4]): OCP MX-fp8 contractions on v_mfma_scale_f32_16x16x128_f8f6f4.
+  * the contraction itself is EXACT arithmetic on the quantised operands (products of e4m3 values and power-of-two scales,
+    fp32 accumulation): checked against an fp64 product of the dequantised operands, all epilogues;
+  * the on-device quantisers (LayerNorm -> MX-fp8, GELU epilogue -> MX-fp8) against the OCP restatement;
+  * the whole forward against the goldens of the imported reference: error statistics + argmax agreement (the reference has
+    no fp8 mode — its only reduced precision is autocast fp16, cell_detection.py:314-316 — so these are reported bounds)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from cellvit_amd import _lib, mx8
+from helpers import load_case
+from test_gpu_forward import _model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / np.sqrt(2.0)))
+
+
+def _mk(M, N, K, seed):
+    rng = np.random.default_rng(seed)
+    # rows of very different magnitude and a few outliers: the block scales must matter
+    A = (rng.standard_normal((M, K)) * np.exp2(rng.integers(-3, 4, (M, 1)))).astype(np.float32)
+    A[rng.integers(0, M, 50), rng.integers(0, K, 50)] *= 30.0
+    W = (rng.standard_normal((N, K)) / np.sqrt(K) * np.exp2(rng.integers(-2, 3, (N, 1)))).astype(np.float32)
+    return A, W, rng
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 768, 1280), (1024, 512, 5120), (4096, 1280, 1280)])
+@pytest.mark.parametrize("mode", ["plain_f32", "bias_res_f32", "gelu_f16"])
+def test_linear_mx8_is_exact_on_the_quantised_operands(M, N, K, mode):
+    A, W, rng = _mk(M, N, K, M + N + K)
+    a8, a_sc = mx8.quantize(A, mx8.A_SIDE)
+    w8, w_sc = mx8.quantize(W, mx8.W_SIDE)
+    _, a_rm = mx8.quantize(A, mx8.ROW_MAJOR)
+    _, w_rm = mx8.quantize(W, mx8.ROW_MAJOR)
+    Ad = mx8.dequantize(a8, a_rm.reshape(M, K // 32))
+    Wd = mx8.dequantize(w8, w_rm.reshape(N, K // 32))
+    ref = torch.from_numpy(Ad) @ torch.from_numpy(Wd).T                       # fp64
+    bias = res = None
+    act, out_kind = 0, 1
+    if mode != "plain_f32":
+        bias = rng.standard_normal(N).astype(np.float32)
+        ref = ref + torch.from_numpy(bias.astype(np.float64))
+    if mode == "bias_res_f32":
+        res = rng.standard_normal((M, N)).astype(np.float32)
+        ref = ref + torch.from_numpy(res.astype(np.float64))
+    if mode == "gelu_f16":
+        act, out_kind = 1, 0
+        ref = _gelu(ref)
+    out = torch.empty((M, N), device=DEV, dtype=torch.float32 if out_kind == 1 else torch.float16)
+    ta, tsa, tw, tsw = _dev(a8), _dev(a_sc), _dev(w8), _dev(w_sc)
+    tb = _dev(bias) if bias is not None else None
+    tr = _dev(res) if res is not None else None
+    _lib.check(_lib.load().cv_op_linear_mx8(_p(ta), _p(tsa), None, _p(tw), _p(tsw), _p(tb), _p(tr), _p(out), out_kind, None, M, N, K,
+                                            act, _stream()))
+    torch.cuda.synchronize()
+    got = out.double().cpu()
+    mag = (torch.from_numpy(np.abs(Ad)) @ torch.from_numpy(np.abs(Wd)).T)     # sum |a b|: scale of the fp32 accumulation error
+    tol = 2e-6 * mag + (2e-3 * ref.abs() + 1e-3 if out_kind == 0 else 1e-6 * ref.abs() + 1e-6)
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), (f"{int(bad.sum())} of {M * N} outputs off; worst {(got - ref).abs().max().item():.3e} "
+                                 f"at {np.unravel_index(int((got - ref).abs().argmax()), (M, N))}")
+
+
+def test_linear_mx8_quantised_output_feeds_the_next_layer():
+    """fc1 -> (GELU, MX-fp8 out) -> fc2 as the engine chains them: the intermediate never exists in higher precision."""
+    M, D, H = 512, 256, 1024
+    A, W1, rng = _mk(M, H, D, 7)
+    W2 = (rng.standard_normal((D, H)) / np.sqrt(H)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(H)).astype(np.float32)
+    a8, a_sc = mx8.quantize(A, mx8.A_SIDE)
+    w18, w1_sc = mx8.quantize(W1, mx8.W_SIDE)
+    w28, w2_sc = mx8.quantize(W2, mx8.W_SIDE)
+    h8 = torch.empty((M, H), device=DEV, dtype=torch.uint8)
+    h_sc = torch.zeros((M * H // 32,), device=DEV, dtype=torch.uint8)
+    out = torch.empty((M, D), device=DEV, dtype=torch.float32)
+    lib = _lib.load()
+    ta, tsa, tw1, ts1, tw2, ts2, tb1 = _dev(a8), _dev(a_sc), _dev(w18), _dev(w1_sc), _dev(w28), _dev(w2_sc), _dev(b1)
+    _lib.check(lib.cv_op_linear_mx8(_p(ta), _p(tsa), None, _p(tw1), _p(ts1), _p(tb1), None, _p(h8), 2, _p(h_sc), M, H, D, 1, _stream()))
+    _lib.check(lib.cv_op_linear_mx8(_p(h8), _p(h_sc), None, _p(tw2), _p(ts2), None, None, _p(out), 1, None, M, D, H, 0, _stream()))
+    torch.cuda.synchronize()
+    # (a) the quantised intermediate against the OCP restatement of quantising gelu(exact product)
+    Ad = mx8.dequantize(a8, mx8.quantize(A, mx8.ROW_MAJOR)[1].reshape(M, D // 32))
+    W1d = mx8.dequantize(w18, mx8.quantize(W1, mx8.ROW_MAJOR)[1].reshape(H, D // 32))
+    hid = _gelu(torch.from_numpy(Ad) @ torch.from_numpy(W1d).T + torch.from_numpy(b1.astype(np.float64))).numpy()
+    sc_dev = mx8.untile_scales(h_sc.cpu().numpy(), M, H, False)
+    hq = mx8.dequantize(h8.cpu().numpy(), sc_dev)
+    _, sc_ref = mx8.quantize(hid.astype(np.float32), mx8.ROW_MAJOR)
+    sc_ref = sc_ref.reshape(M, H // 32)
+    agree = float((sc_dev == sc_ref).mean())
+    assert agree > 0.999, agree                                           # a block maximum on an exponent boundary may differ by 1 ulp of GELU
+    blk = np.abs(hid.reshape(M, H // 32, 32)).max(-1, keepdims=True).repeat(32, -1).reshape(M, H)
+    assert (np.abs(hq - hid) <= np.maximum(np.abs(hid) * 2.0 ** -3, blk * 2.0 ** -16) + 1e-6).all()
+    # (b) the second contraction is exact on whatever the first one wrote
+    W2d = mx8.dequantize(w28, mx8.quantize(W2, mx8.ROW_MAJOR)[1].reshape(D, H // 32))
+    ref = torch.from_numpy(hq) @ torch.from_numpy(W2d).T
+    mag = torch.from_numpy(np.abs(hq)) @ torch.from_numpy(np.abs(W2d)).T
+    assert bool(((out.double().cpu() - ref).abs() <= 2e-6 * mag + 1e-6).all())
+
+
+@pytest.mark.parametrize("with_delta", [False, True])
+def test_layernorm_mx8(with_delta):
+    M, Cn = 512, 1280
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((M, Cn), generator=g) * 3.0 + 0.5
+    x[5, 100] = 80.0                                                       # an outlier token feature
+    delta = (torch.randn((M, Cn), generator=g) * 0.5).half() if with_delta else None
+    gamma = torch.rand(Cn, generator=g) + 0.5
+    beta = torch.randn(Cn, generator=g) * 0.1
+    xd = x.to(DEV).clone()
+    out8 = torch.empty((M, Cn), device=DEV, dtype=torch.uint8)
+    sca = torch.zeros((M * Cn // 32,), device=DEV, dtype=torch.uint8)
+    scw = torch.zeros((M * Cn // 32,), device=DEV, dtype=torch.uint8)
+    dd = delta.to(DEV) if with_delta else None
+    _lib.check(_lib.load().cv_op_layernorm_mx8(_p(xd), _p(dd), _p(gamma.to(DEV)), _p(beta.to(DEV)), _p(out8), _p(sca), _p(scw), M, Cn,
+                                               1e-6, _stream()))
+    torch.cuda.synchronize()
+    xin = x + (delta.float() if with_delta else 0.0)
+    if with_delta:
+        assert torch.equal(xd.cpu(), xin), "the residual stream must be updated with x + delta"
+    ref = torch.nn.functional.layer_norm(xin, (Cn,), gamma, beta, 1e-6).numpy()
+    sa = mx8.untile_scales(sca.cpu().numpy(), M, Cn, False)
+    sw = mx8.untile_scales(scw.cpu().numpy(), M, Cn, True)
+    assert np.array_equal(sa, sw), "A-side and W-side scale images must hold the same scales"
+    d_ref, s_ref = mx8.quantize(ref, mx8.ROW_MAJOR)
+    s_ref = s_ref.reshape(M, Cn // 32)
+    assert float((sa == s_ref).mean()) > 0.999
+    same = np.repeat(sa == s_ref, 32, axis=1)
+    mism = float((out8.cpu().numpy()[same] != d_ref[same]).mean())
+    assert mism < 2e-3, mism                                               # fp32 LayerNorm differs from torch's by ulps: rare rounding flips
+    deq = mx8.dequantize(out8.cpu().numpy(), sa)
+    blk = np.abs(ref.reshape(M, Cn // 32, 32)).max(-1, keepdims=True).repeat(32, -1).reshape(M, Cn)
+    assert (np.abs(deq - ref) <= np.maximum(np.abs(ref) * 2.0 ** -3, blk * 2.0 ** -16) + 1e-6).all()
+
+
+@pytest.mark.parametrize("win", [0, 14])
+def test_attention_layer_mx8_vs_fp16(win):
+    """The fused qkv projection on MX-fp8 operands (incl. the operand-exchanged V tiles and the window scatter) + attention,
+    against the fp16 layer on the dequantised inputs (the only difference left is fp16 rounding of the GEMM operands)."""
+    B, gh, gw, heads, D = 1, 16, 16, 4, 256
+    hd = D // heads
+    rng = np.random.default_rng(win)
+    X = rng.standard_normal((B * gh * gw, D)).astype(np.float32)
+    Wq = (rng.standard_normal((3 * D, D)) / np.sqrt(D)).astype(np.float32)
+    bq = (0.1 * rng.standard_normal(3 * D)).astype(np.float32)
+    side = win if win else gh
+    th = (0.02 * rng.standard_normal((2 * side - 1, hd))).astype(np.float32)
+    tw = (0.02 * rng.standard_normal((2 * side - 1, hd))).astype(np.float32)
+    x8, xs_a = mx8.quantize(X, mx8.A_SIDE)
+    _, xs_w = mx8.quantize(X, mx8.W_SIDE)
+    _, xs_rm = mx8.quantize(X, mx8.ROW_MAJOR)
+    # weight image as cv_finalize packs it: V rows (>= 2D) in the A-side order, q / k rows W-side
+    w8, ws_rm = mx8.quantize(Wq, mx8.ROW_MAJOR)
+    ws_rm = ws_rm.reshape(3 * D, D // 32)
+    ia, iw = mx8.scale_index(3 * D, D, False), mx8.scale_index(3 * D, D, True)
+    ws = np.zeros(3 * D * D // 32, np.uint8)
+    ws[iw[:2 * D].reshape(-1)] = ws_rm[:2 * D].reshape(-1)
+    ws[ia[2 * D:].reshape(-1)] = ws_rm[2 * D:].reshape(-1)
+    lib = _lib.load()
+    out8 = torch.empty((B * gh * gw, D), device=DEV, dtype=torch.float16)
+    tx8, txa, txw, tw8, tws, tbq, tth, ttw = _dev(x8), _dev(xs_a), _dev(xs_w), _dev(w8), _dev(ws), _dev(bq), _dev(th), _dev(tw)
+    _lib.check(lib.cv_op_attention_mx8(_p(tx8), _p(txa), _p(txw), _p(tw8), _p(tws), _p(tbq), _p(tth), _p(ttw), _p(out8), B, gh, gw,
+                                       heads, D, win, _stream()))
+    Xd = mx8.dequantize(x8, xs_rm.reshape(-1, D // 32)).astype(np.float32)
+    Wd = mx8.dequantize(w8, ws_rm).astype(np.float32)
+    out16 = torch.empty_like(out8)
+    txd, twd = _dev(Xd).half(), _dev(Wd).half()
+    _lib.check(lib.cv_op_attention(_lib.DTYPE_F16, _p(txd), _p(twd), _p(tbq), _p(tth), _p(ttw), _p(out16), B, gh, gw, 0, heads, D, win,
+                                   _stream()))
+    torch.cuda.synchronize()
+    d = (out8.float() - out16.float()).abs().max().item()
+    print(f"\n[attention mx8 vs fp16, win={win}] max abs diff {d:.3e} (output abs max {out16.float().abs().max().item():.3f})")
+    assert d < 2e-2, d
+
+
+def test_fp8_engine_is_refused_where_it_does_not_apply():
+    from cellvit_amd.model import CellViT256
+    from cellvit_amd.spec import cellvit256_config
+    from cellvit_amd.weights import make_state_dict
+    m = CellViT256(None, 6, 19, compute_dtype="fp8")
+    m.load_state_dict(make_state_dict(cellvit256_config(), 0))
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 3, 256, 256, device=DEV))
+
+
+@pytest.mark.parametrize("name", ["samh_256", "samh_1024"])
+def test_forward_fp8_error_statistics(name):
+    """configs[4]: SAM-H, MX-fp8 qkv / fc1 / fc2, against the goldens of the imported (fp32) reference.  Stated tolerance
+    (what three fp8 contractions per block over 32 blocks hold): logits max-abs < 0.25, mean-abs < 0.03, argmax agreement
+    >= 0.97 / 0.95 — and for reference the same statistics of the fp16 engine are printed next to them."""
+    cfg, sd, x, gold = load_case(name)
+    stats = {}
+    for dt in ("fp16", "fp8"):
+        m = _model(cfg, sd, dt)
+        out = m(x.cuda(), retrieve_tokens=True)
+        torch.cuda.synchronize()
+        st = {}
+        for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
+            a = out[k].float().cpu().numpy()
+            if k in gold:
+                gk, ak = gold[k], a
+            else:                                        # 1024^2 goldens are centre / corner crops
+                c = gold[k + "_center"].shape[-1]
+                H = a.shape[-1]
+                y0 = (H - c) // 2
+                gk = np.concatenate([gold[k + "_center"], gold[k + "_corner"]], 0)
+                ak = np.concatenate([a[..., y0:y0 + c, y0:y0 + c], a[..., :c, :c]], 0)
+            st[k] = (float(np.abs(ak - gk).max()), float(np.abs(ak - gk).mean()))
+            if k != "hv_map":
+                st[k + "_argmax"] = float((ak.argmax(1) == gk.argmax(1)).mean())
+        stats[dt] = st
+        del m, out
+    print(f"\n[{name}] (max abs, mean abs) / argmax agreement vs the imported reference:\n   fp16 {stats['fp16']}\n   fp8  {stats['fp8']}")
+    s8 = stats["fp8"]
+    for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
+        assert s8[k][0] < 0.25 and s8[k][1] < 0.03, (k, s8[k])
+    assert s8["nuclei_binary_map_argmax"] >= 0.97 and s8["nuclei_type_map_argmax"] >= 0.95, s8

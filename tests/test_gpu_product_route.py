@@ -136,8 +136,8 @@ def test_forward_u8_equals_forward_of_the_normalised_tensor(dtype):
     u8 = torch.from_numpy(np.stack([synthetic_tile_u8(i, size=256, he_like=bool(i)) for i in range(2)])).cuda()
     # T.ToTensor: uint8 HWC -> float CHW / 255 ; T.Normalize: (x - mean) / std      (torch ops = the reference transform)
     ref = u8.permute(0, 3, 1, 2).float().div(255.0)
-    ref = (ref - torch.tensor(mean, device="cuda").view(1, 3, 1, 1)) / torch.tensor(std, device="cuda").view(1, 3, 1, 1)
-    nrm = torch.empty_like(ref)
+    ref = ((ref - torch.tensor(mean, device="cuda").view(1, 3, 1, 1)) / torch.tensor(std, device="cuda").view(1, 3, 1, 1)).contiguous()
+    nrm = torch.empty((2, 3, 256, 256), device="cuda", dtype=torch.float32)
     _lib.check(_lib.load().cv_op_normalize_u8(u8.data_ptr(), (C.c_float * 3)(*mean), (C.c_float * 3)(*std), nrm.data_ptr(), 2, 256,
                                               256, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
@@ -159,7 +159,7 @@ def test_pool_cell_tokens_matches_the_reference_formula():
     from cellvit_amd.postproc import _params, pool_cell_tokens, postprocess_device, records_to_dicts
     from cellvit_amd.synth import synth_nuclei_maps
     B, T, D = 3, 512, 384
-    maps = [synth_nuclei_maps(40 + i, T, 150 + 40 * i) for i in range(B)]
+    maps = [synth_nuclei_maps(40 + i, T, 800 + 200 * i) for i in range(B)]
     dev = torch.device("cuda", 0)
     tm = torch.from_numpy(np.stack([m[0] for m in maps])).to(dev)
     bm = torch.from_numpy(np.stack([m[1] for m in maps])).to(dev)
@@ -194,16 +194,16 @@ def test_capacity_overflow_is_reported():
     """more instances / contour points than the handle holds must raise, not return truncated arrays."""
     from cellvit_amd import postproc as PP
     from cellvit_amd.synth import synth_nuclei_maps
-    tm, bm, hv, _ = synth_nuclei_maps(3, 512, 400)
+    tm, bm, hv, _ = synth_nuclei_maps(3, 512, 2400)              # ~500 instances on the 512^2 tile
     dev = torch.device("cuda", 0)
     args = (torch.from_numpy(bm)[None].to(dev), torch.from_numpy(tm)[None].to(dev), torch.from_numpy(hv)[None].to(dev), 6, 10, 21)
     try:
-        PP.set_capacity(inst_div=512 * 512 // 256, pts_div=8)            # 256 record slots < ~400 cells
+        PP.set_capacity(inst_div=512 * 512 // 256, pts_div=8)            # 256 record slots < ~500 cells
         inst, recs, n_recs, contours, n_pts = PP.postprocess_device(*args)
         assert int(n_recs[0]) > recs.shape[1]
         with pytest.raises(PP.CapacityError):
             PP.records_to_dicts(recs, n_recs, contours, n_pts)
-        PP.set_capacity(inst_div=128, pts_div=512 * 512 // 4096)         # 4096 contour points < what 400 cells need
+        PP.set_capacity(inst_div=128, pts_div=512 * 512 // 4096)         # 4096 contour points < what ~500 cells need
         inst2, recs2, n_recs2, contours2, n_pts2 = PP.postprocess_device(*args)
         assert int(n_pts2[0]) > contours2.shape[1]
         with pytest.raises(PP.CapacityError):
