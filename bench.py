@@ -34,7 +34,11 @@ sys.path.insert(0, ROOT)
 
 METRIC = "1024x1024 tiles/sec end-to-end (fwd+postproc), CellViT-SAM-H"
 MFMA_F16_PEAK_TFLOPS = 2500.0       # dense, /opt/skills/guides/MI355X_MICROARCH.md
-KCLASS = ["gemm_linear(proj/fc1/fc2/patch/neck)", "gemm_qkv", "conv3x3_implicit_gemm", "convT2x2_gemm", "attention"]
+MFMA_F8_PEAK_TFLOPS = 5000.0        # dense MX-fp8 (K = 128 block-scaled MFMA), same guide
+KCLASS = ["gemm_linear(proj/fc1/fc2/patch/neck)", "gemm_qkv", "conv3x3_implicit_gemm", "convT2x2_gemm", "attention",
+          "gemm_mx8(qkv/fc1/fc2, MX-fp8)"]
+KPEAK = [MFMA_F16_PEAK_TFLOPS] * 5 + [MFMA_F8_PEAK_TFLOPS]
+NK = len(KCLASS)
 
 
 def parse():
@@ -250,14 +254,15 @@ def main():
         roofline = None
         kstats = {}
         if kernel_events:
-            ms = (C.c_double * 5)(); n = (C.c_int64 * 5)(); fl = (C.c_double * 5)()
+            ms = (C.c_double * NK)(); n = (C.c_int64 * NK)(); fl = (C.c_double * NK)()
             _lib.check(eng.lib.cv_profile_collect(eng.h, ms, n, fl))
             _lib.check(eng.lib.cv_profile_enable(eng.h, 0))
             for i, name in enumerate(KCLASS):
                 if n[i]:
                     kstats[name] = {"launches": int(n[i]), "avg_us": 1e3 * ms[i] / n[i], "total_ms_per_step": ms[i] / args.steps,
-                                    "tflops": fl[i] / (ms[i] * 1e-3) / 1e12}
-            dom = max(range(5), key=lambda i: ms[i])
+                                    "tflops": fl[i] / (ms[i] * 1e-3) / 1e12, "peak_tflops": KPEAK[i],
+                                    "frac": fl[i] / (ms[i] * 1e-3) / 1e12 / KPEAK[i]}
+            dom = max(range(NK), key=lambda i: ms[i])
             ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -266,8 +271,8 @@ def main():
                     traffic = json.load(open(tpath)).get(KCLASS[dom])
                 except Exception:
                     traffic = None
-            roofline = {"bound": "mfma", "kernel": KCLASS[dom], "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS,
+            roofline = {"bound": "mfma", "kernel": KCLASS[dom], "achieved": ach, "peak": KPEAK[dom],
+                        "unit": "TFLOP/s", "frac": ach / KPEAK[dom],
                         "flops_per_launch": fl[dom] / n[dom], "avg_launch_us": 1e3 * ms[dom] / n[dom],
                         "launches": int(n[dom]), "traffic": traffic,
                         "traffic_source": "profiles/traffic_latest.json: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, "
@@ -284,7 +289,11 @@ def main():
                        "postproc": bool(do_pp), "postproc_stream_overlap": bool(overlap), "postproc_input": f"synthetic nuclei maps, {args.cells} cells/tile",
                        "instances_per_step": n_inst},
             "stage_ms_sequential": {"forward": fwd_ms, "postproc": pp_ms},
-            "whole_forward_mfma_frac": (B * flops_per_tile / (fwd_ms * 1e-3)) / (MFMA_F16_PEAK_TFLOPS * 1e12),
+            # forward time at 100 % of the MFMA peak(s) / measured forward time.  f8: the qkv / fc1 / fc2 share of the algorithmic
+            # FLOPs (11/12 of the encoder's 5.154 TFLOP of linear layers per 1024^2 SAM-H tile) is priced at the MX-fp8 peak
+            "whole_forward_mfma_frac": (B * (flops_per_tile / (MFMA_F16_PEAK_TFLOPS * 1e12)) / (fwd_ms * 1e-3)) if args.dtype == "f16" or args.model != "samh"
+            else (B * ((4.7245e12 * (T / 1024.0) ** 2) / (MFMA_F8_PEAK_TFLOPS * 1e12) +
+                       (flops_per_tile - 4.7245e12 * (T / 1024.0) ** 2) / (MFMA_F16_PEAK_TFLOPS * 1e12)) / (fwd_ms * 1e-3)),
             "roofline": roofline,
             "kernel_classes": kstats,
         }

@@ -33,7 +33,7 @@ using namespace cva;
 // live per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
 // ------------------------------------------------------------------------------------------------
 namespace {
-enum { KC_GEMM_LINEAR = 0, KC_GEMM_QKV = 1, KC_CONV3 = 2, KC_CONVT = 3, KC_ATTN = 4, KC_COUNT = 5 };
+enum { KC_GEMM_LINEAR = 0, KC_GEMM_QKV = 1, KC_CONV3 = 2, KC_CONVT = 3, KC_ATTN = 4, KC_GEMM_MX8 = 5, KC_COUNT = 6 };
 struct Profiler {
     bool on = false;
     struct Rec { hipEvent_t a, b; int cls; double flops; };
@@ -401,7 +401,7 @@ int run_linear_mx8(const void* A8, const void* a_sc, int lda, const LinearW& w, 
     p.a_scale = a_sc; p.w_scale = w.S8;
     p.bias = w.bias; p.act = act; p.res = res; p.ldres = ldres;
     p.out_mode = out_mode; p.out_f32 = out_f32; p.out = out; p.ldc = ldc; p.out_scale = out_sc;
-    ProfScope ps(KC_GEMM_LINEAR, 2.0 * M * (double)w.N * w.K, st);
+    ProfScope ps(KC_GEMM_MX8, 2.0 * M * (double)w.N * w.K, st);
     const int rc = launch_gemm8_f8(p, st);
     if (rc) { cva_set_error("fp8 gemm launch failed (%d): M=%d N=%d K=%d", rc, M, w.N, w.K); return rc == (int)hipErrorInvalidValue ? CV_ERR_UNSUPPORTED : CV_ERR_HIP; }
     return CV_OK;
@@ -473,7 +473,7 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
     g.win = window ? ws : 0; g.gw = gw; g.gh = gh; g.nwx = nwx; g.nwy = nwy;
     if (xn_sca) {      // fp8 engine: xn is the MX-fp8 image written by the LayerNorm, qkv.W8 / S8 the packed weight
         g.W = qkv.W8; g.ldw = qkv.K; g.a_scale = xn_sca; g.a_scale_w = xn_scw; g.w_scale = qkv.S8;
-        ProfScope ps(KC_GEMM_QKV, 2.0 * g.M * (double)g.N * g.K, st);
+        ProfScope ps(KC_GEMM_MX8, 2.0 * g.M * (double)g.N * g.K, st);
         const int rc8 = launch_gemm8_f8(g, st);
         if (rc8) { cva_set_error("fp8 qkv gemm launch failed (%d)", rc8); return rc8 == (int)hipErrorInvalidValue ? CV_ERR_UNSUPPORTED : CV_ERR_HIP; }
     } else { ProfScope ps(KC_GEMM_QKV, 2.0 * g.M * (double)g.N * g.K, st); CVA_LAUNCH(launch_gemm<T>(g, A_LINEAR, st)); }
@@ -1269,7 +1269,7 @@ extern "C" int cv_profile_enable(cv_handle* h, int on) {
     return CV_OK;
 }
 
-// Synchronises; accumulates per class: total_ms[KC], launches[KC], flops[KC] (arrays of 5) and resets.
+// Synchronises; accumulates per class: total_ms[KC], launches[KC], flops[KC] (arrays of 6) and resets.
 extern "C" int cv_profile_collect(cv_handle* h, double* total_ms, int64_t* launches, double* flops) {
     if (!h || !total_ms || !launches || !flops) return CV_ERR_INVALID;
     for (int i = 0; i < KC_COUNT; ++i) { total_ms[i] = 0; launches[i] = 0; flops[i] = 0; }

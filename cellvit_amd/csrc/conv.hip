@@ -35,7 +35,9 @@ constexpr int MAX_W = (W_INSTR + NWAVE - 1) / NWAVE;      // 5
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
-template <int MINW>
+// ABL (ablation builds only, CVA_CONV_DBG): 1 = stage the filter taps of the first chunk only, 2 = the halo of the first
+// chunk only, 4 = no MFMAs — timing experiments, results are wrong by construction.
+template <int MINW, int ABL = 0>
 __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParams p) {
     using TR = Traits<half_t>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
     } while (0)
 #define CV_MMA_TAP(S)                                                                                           \
     do {                                                                                                        \
+        if (!(ABL & 4))                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[S][i], Bf[S][j], acc[i][j], 0, 0, 0);     \
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
 #pragma unroll
         for (int i = 0; i < MAX_H; ++i) {
             const int k = wave + NWAVE * i;
-            if (k < HALO_INSTR) {                     // wave-uniform
+            if (k < HALO_INSTR && !((ABL & 2) && ch > 0)) {                     // wave-uniform
                 const half_t* s = h_pix[i] >= 0 ? src + (long)(h_pix[i] >> 2) * cs + cc + (h_pix[i] & 3) * 8 : Zp;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
                                                  (__attribute__((address_space(3))) void*)(dH + k * 1024), 16, 0, 0);
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
 #pragma unroll
         for (int i = 0; i < MAX_W; ++i) {
             const int k = wave + NWAVE * i;
-            if (k < W_INSTR) {
+            if (k < W_INSTR && !((ABL & 1) && ch > 0)) {
                 const half_t* s = w_row[i] >= 0 ? Wp + w_row[i] + c0 : Zp;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
                                                  (__attribute__((address_space(3))) void*)(dW + k * 1024), 16, 0, 0);
@@ -285,6 +288,16 @@ int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
     }
     const int tiles = batch * ((p.H + TH - 1) / TH) * ((p.Wd + TW - 1) / TW);
     const dim3 grid(tiles * ((p.N + 63) / 64));
+#ifdef CVA_ABLATION
+    static const int dbg = cva_env_int("CVA_CONV_DBG", 0);
+    if (dbg) {
+        static bool attr = false;
+#define CVA_CONV_ABL(A) do { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<2, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+                             hipLaunchKernelGGL((conv3x3_halo_kernel<2, A>), grid, dim3(NTH), 2 * CONV_LDS, stream, p); return (int)hipGetLastError(); } while (0)
+        switch (dbg) { case 1: CVA_CONV_ABL(1); case 2: CVA_CONV_ABL(2); case 3: CVA_CONV_ABL(3); case 4: CVA_CONV_ABL(4); case 7: CVA_CONV_ABL(7); default: break; }
+#undef CVA_CONV_ABL
+    }
+#endif
     if (occ == 2) hipLaunchKernelGGL(conv3x3_halo_kernel<2>, grid, dim3(NTH), 2 * CONV_LDS, stream, p);
     else hipLaunchKernelGGL(conv3x3_halo_kernel<4>, grid, dim3(NTH), 2 * CONV_LDS, stream, p);
     return (int)hipGetLastError();

@@ -40,9 +40,10 @@
 // configs[4]).  A tile row is still 128 bytes = 128 K elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 step (8 passes, twice
 // the FLOPs per cycle of the fp16 instruction), so the LDS image, the DMA, the number of fragment reads and the phase
 // table carry over unchanged; what differs:
-//   * a lane's operand is 32 CONTIGUOUS bytes of its row (k block g = lane >> 4: pieces 2g, 2g + 1) so that it is exactly one
-//     scale block; the source-side swizzle is piece ^ f((row >> 1) & 7), f(b2 b1 b0) = (b2, b0, b2 ^ b1), which keeps the four
-//     16-lane groups of both ds_read_b128 conflict free for this piece assignment;
+//   * the K order of the instruction (measured, tools/probes/probe_mfma_scale.hip): lane (g, li) supplies row li's bytes
+//     K[16g, 16g+16) in its first four VGPRs and K[64+16g, 64+16g+16) in the last four — the SAME two 16-byte pieces (g, g + 4)
+//     the fp16 path reads for its two k steps, so fragment addresses and the XOR swizzle are shared — while the E8M0 scale of
+//     K block j = K[32j, 32j+32) is taken from the scale VGPR of the lanes with g = j (byte chosen by op_sel);
 //   * the scales of a K tile (256 rows x 4 blocks = 1 KiB per operand) ride in with the tile's A stage as ONE extra
 //     global_load_lds_dword per wave and are stored in global memory already in the order the fragment reads want them:
 //     ONE ds_read_b32 hands a lane the scales of the four fragments of a sub-tile, selected per MFMA by op_sel
@@ -389,12 +390,6 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
     }
 }
 
-// swizzle of the 16-byte piece index inside a 128-byte LDS row, as a function of h = (row >> 1) & 7 (applied on the DMA
-// source side and in the fragment reads): fp16 h itself; fp8 f(b2 b1 b0) = (b2, b0, b2 ^ b1) (see the file header)
-template <int F8> __device__ __forceinline__ int g8_swz(int h) {
-    return F8 ? ((h & 4) | ((h & 1) << 1) | (((h >> 2) ^ (h >> 1)) & 1)) : h;
-}
-
 template <int OMODE, int TRANS, int ABL, int F8>
 __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
@@ -438,7 +433,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave * 32 + i * 8 + lrow;
-            const int lp = lpc ^ g8_swz<F8>((row >> 1) & 7);
+            const int lp = lpc ^ ((row >> 1) & 7);
             // TRANS: LDS row wc*64 + j*16 + g*4 + r of the "W" tile holds source row wc*64 + g*16 + j*4 + r, so that a
             // lane's 16 accumulator values per output row are 16 consecutive columns (see epilogue8_direct)
             const int prow = TRANS == 1 ? ((row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3)) : row;
@@ -456,7 +451,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             // scale images: activations  A-side layout p.a_scale (p.a_scale_w = W-side layout, for the swapped V tiles);
             //               weights      p.w_scale, packed per 256-row tile in the layout of the side the tile runs on
             const bool a_side = wave < 4;
-            const unsigned char* act = reinterpret_cast<const unsigned char*>(a_side == !swap ? p.a_scale : p.a_scale_w);
+            const unsigned char* act = reinterpret_cast<const unsigned char*>(a_side ? p.a_scale : p.a_scale_w);   // image of the side they land on
             const unsigned char* wgt = reinterpret_cast<const unsigned char*>(p.w_scale);
             const bool take_act = a_side == !swap;          // A side holds activations unless swapped
             Sb = take_act ? act + (long)(m0 / G8_BM) * nk * 1024 : wgt + (long)(n0 / G8_BN) * nk * 1024;
@@ -492,10 +487,10 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     };
 
     // ---- fragment read offsets: row r (r & 15 == lane & 15), logical piece ks*4 + g -> byte r*128 + ((lp ^ ((r>>1)&7)) << 4)
-    // (F8: logical pieces 2g and 2g + 1 -> byte li*128 + (((2g) ^ f) << 4) and that ^ 16)
+    // (fp8: the same two pieces g and g + 4 form the lane's 32-byte operand of the K = 128 instruction, see the file header)
     const int g = lane >> 4, li = lane & 15;
-    const int off0 = li * 128 + (((F8 ? 2 * g : g) ^ g8_swz<F8>((li >> 1) & 7)) << 4);
-    const int d1 = F8 ? 16 - 2 * (off0 & 16) : 64 - 2 * (off0 & 64);   // offset of the second piece: off ^ 64 (fp16: k step 1), off ^ 16 (fp8)
+    const int off0 = li * 128 + ((g ^ ((li >> 1) & 7)) << 4);
+    const int d1 = 64 - 2 * (off0 & 64);                          // offset of the second piece (g + 4): off ^ 64
     const unsigned a_ad0 = lds0 + (wr * 128) * 128 + off0, a_ad1 = a_ad0 + d1;              // + buf*32K + mh*8K + mi*2K
     const unsigned w_ad0 = lds0 + G8_WOFF + (wc * 64) * 128 + off0, w_ad1 = w_ad0 + d1;     // + buf*32K + nh*4K + nj*2K
 

@@ -122,8 +122,9 @@ int cv_set_debug(cv_handle* h, int enable);
 int cv_debug_read(cv_handle* h, const char* name, float* host_dst, size_t capacity, size_t* n_out);
 
 /* Live per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
- * class while enabled).  Classes: 0 linear GEMM, 1 QKV GEMM, 2 conv3x3, 3 convT2x2, 4 attention.
- * cv_profile_collect synchronises, fills three arrays of 5 (ms, launches, algorithmic FLOPs) and resets. */
+ * class while enabled).  Classes: 0 linear GEMM (fp16), 1 QKV GEMM (fp16), 2 conv3x3, 3 convT2x2, 4 attention,
+ * 5 MX-fp8 GEMMs of the fp8 engine (qkv, fc1, fc2).
+ * cv_profile_collect synchronises, fills three arrays of 6 (ms, launches, algorithmic FLOPs) and resets. */
 int cv_profile_enable(cv_handle* h, int on);
 int cv_profile_collect(cv_handle* h, double* total_ms, int64_t* launches, double* flops);
 

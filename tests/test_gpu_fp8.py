@@ -130,8 +130,8 @@ def test_layernorm_mx8(with_delta):
     sca = torch.zeros((M * Cn // 32,), device=DEV, dtype=torch.uint8)
     scw = torch.zeros((M * Cn // 32,), device=DEV, dtype=torch.uint8)
     dd = delta.to(DEV) if with_delta else None
-    _lib.check(_lib.load().cv_op_layernorm_mx8(_p(xd), _p(dd), _p(gamma.to(DEV)), _p(beta.to(DEV)), _p(out8), _p(sca), _p(scw), M, Cn,
-                                               1e-6, _stream()))
+    gd, bd = gamma.to(DEV), beta.to(DEV)                                   # (keep the device copies alive across the launch)
+    _lib.check(_lib.load().cv_op_layernorm_mx8(_p(xd), _p(dd), _p(gd), _p(bd), _p(out8), _p(sca), _p(scw), M, Cn, 1e-6, _stream()))
     torch.cuda.synchronize()
     xin = x + (delta.float() if with_delta else 0.0)
     if with_delta:

@@ -134,9 +134,10 @@ def test_forward_u8_equals_forward_of_the_normalised_tensor(dtype):
     m = _model(cfg, sd, dtype)
     mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
     u8 = torch.from_numpy(np.stack([synthetic_tile_u8(i, size=256, he_like=bool(i)) for i in range(2)])).cuda()
-    # T.ToTensor: uint8 HWC -> float CHW / 255 ; T.Normalize: (x - mean) / std      (torch ops = the reference transform)
-    ref = u8.permute(0, 3, 1, 2).float().div(255.0)
-    ref = ((ref - torch.tensor(mean, device="cuda").view(1, 3, 1, 1)) / torch.tensor(std, device="cuda").view(1, 3, 1, 1)).contiguous()
+    # T.ToTensor: uint8 HWC -> float CHW / 255 ; T.Normalize: (x - mean) / std — torch CPU ops, where the reference's
+    # DataLoader workers run them (IEEE division; torch's GPU kernels may multiply by a reciprocal instead)
+    ref = u8.cpu().permute(0, 3, 1, 2).float().div(255.0)
+    ref = ((ref - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)).contiguous().cuda()
     nrm = torch.empty((2, 3, 256, 256), device="cuda", dtype=torch.float32)
     _lib.check(_lib.load().cv_op_normalize_u8(u8.data_ptr(), (C.c_float * 3)(*mean), (C.c_float * 3)(*std), nrm.data_ptr(), 2, 256,
                                               256, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
