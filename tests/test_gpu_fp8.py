@@ -73,8 +73,10 @@ def test_linear_mx8_is_exact_on_the_quantised_operands(M, N, K, mode):
                                             act, _stream()))
     torch.cuda.synchronize()
     got = out.double().cpu()
-    mag = (torch.from_numpy(np.abs(Ad)) @ torch.from_numpy(np.abs(Wd)).T)     # sum |a b|: scale of the fp32 accumulation error
-    tol = 2e-6 * mag + (2e-3 * ref.abs() + 1e-3 if out_kind == 0 else 1e-6 * ref.abs() + 1e-6)
+    # sum |a b| sets the scale of the accumulation error: the instruction adds its 128 products in an aligned window before
+    # the fp32 accumulate (measured <= 1.7e-5 of sum |a b| on this data; the products themselves are exact)
+    mag = (torch.from_numpy(np.abs(Ad)) @ torch.from_numpy(np.abs(Wd)).T)
+    tol = 4e-5 * mag + (2e-3 * ref.abs() + 1e-3 if out_kind == 0 else 1e-6 * ref.abs() + 1e-6)
     bad = (got - ref).abs() > tol
     assert not bool(bad.any()), (f"{int(bad.sum())} of {M * N} outputs off; worst {(got - ref).abs().max().item():.3e} "
                                  f"at {np.unravel_index(int((got - ref).abs().argmax()), (M, N))}")
@@ -108,12 +110,13 @@ def test_linear_mx8_quantised_output_feeds_the_next_layer():
     agree = float((sc_dev == sc_ref).mean())
     assert agree > 0.999, agree                                           # a block maximum on an exponent boundary may differ by 1 ulp of GELU
     blk = np.abs(hid.reshape(M, H // 32, 32)).max(-1, keepdims=True).repeat(32, -1).reshape(M, H)
-    assert (np.abs(hq - hid) <= np.maximum(np.abs(hid) * 2.0 ** -3, blk * 2.0 ** -16) + 1e-6).all()
+    pre = 1.2 * 4e-5 * (np.abs(Ad) @ np.abs(W1d).T) + 2e-5                # error of the value BEFORE quantisation: accumulate window, GELU table
+    assert (np.abs(hq - hid) <= np.maximum(np.abs(hid) * 2.0 ** -3, blk * 2.0 ** -16) + 1.2 * pre + 1e-6).all()
     # (b) the second contraction is exact on whatever the first one wrote
     W2d = mx8.dequantize(w28, mx8.quantize(W2, mx8.ROW_MAJOR)[1].reshape(D, H // 32))
     ref = torch.from_numpy(hq) @ torch.from_numpy(W2d).T
     mag = torch.from_numpy(np.abs(hq)) @ torch.from_numpy(np.abs(W2d)).T
-    assert bool(((out.double().cpu() - ref).abs() <= 2e-6 * mag + 1e-6).all())
+    assert bool(((out.double().cpu() - ref).abs() <= 4e-5 * mag + 1e-6).all())
 
 
 @pytest.mark.parametrize("with_delta", [False, True])
