@@ -265,7 +265,7 @@ def main():
             dom = max(range(NK), key=lambda i: ms[i])
             ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json" if args.dtype == "f16" else "traffic_f8.json")
             if os.path.exists(tpath):
                 try:
                     traffic = json.load(open(tpath)).get(KCLASS[dom])
@@ -275,7 +275,7 @@ def main():
                         "unit": "TFLOP/s", "frac": ach / KPEAK[dom],
                         "flops_per_launch": fl[dom] / n[dom], "avg_launch_us": 1e3 * ms[dom] / n[dom],
                         "launches": int(n[dom]), "traffic": traffic,
-                        "traffic_source": "profiles/traffic_latest.json: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, "
+                        "traffic_source": os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, "
                                           "corrected per MI355X_MICROARCH.md (tools/pmc_traffic.py); not collected in this run"
                                           if traffic is not None else None}
         rec = {

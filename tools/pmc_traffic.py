@@ -16,13 +16,14 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASSES = [  # (key in the json, substring of the kernel name)
+CLASSES = [  # (key in the json, substring of the kernel name); gemm8_kernel<OMODE, TRANS, ABL, F8>
+    ("mx8", "gemm8_kernel<0, 1, 0, 1>"), ("mx8", "gemm8_kernel<1, 1, 0, 1>"), ("mx8", "gemm8_kernel<3, 1, 0, 1>"),
     ("linear", "gemm8_kernel<0"), ("qkv", "gemm8_kernel<1"), ("convT", "gemm8_kernel<2"), ("conv", "conv3x3_halo_kernel"),
-    ("attn_global", "attn2_kernel"), ("attn_win", "attnwp_kernel"), ("layernorm", "layernorm_kernel"),
-    ("layernorm_add", "layernorm_add_kernel"),
+    ("attn_global", "attn2_kernel"), ("attn_win", "attnwp_kernel"), ("layernorm_mx8", "layernorm_mx8_kernel"),
+    ("layernorm", "layernorm_kernel"), ("layernorm_add", "layernorm_add_kernel"),
 ]
 BENCH_KEYS = {"linear": "gemm_linear(proj/fc1/fc2/patch/neck)", "qkv": "gemm_qkv", "conv": "conv3x3_implicit_gemm",
-              "convT": "convT2x2_gemm"}
+              "convT": "convT2x2_gemm", "mx8": "gemm_mx8(qkv/fc1/fc2, MX-fp8)"}
 
 
 def per_launch(directory, counter):
@@ -49,7 +50,7 @@ def main():
     write = per_launch(wdir, "WRITE_SIZE")
     out = {"_how": __doc__.split("\n\n")[1].replace("\n", " ").strip() + "  " + __doc__.split("\n\n")[2].replace("\n", " ").strip()}
     detail = {}
-    for key, _ in CLASSES:
+    for key in dict.fromkeys(k for k, _ in CLASSES):
         if key in fetch or key in write:
             f2 = 2.0 * fetch.get(key, 0.0) * 1024.0
             w = write.get(key, 0.0) * 1024.0
@@ -57,7 +58,7 @@ def main():
             if key in BENCH_KEYS:
                 out[BENCH_KEYS[key]] = f2 + w
     out["_detail_MiB_per_launch"] = detail
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    path = os.path.join(ROOT, "profiles", sys.argv[3] if len(sys.argv) > 3 else "traffic_latest.json")
     out["_tiles_per_step"] = "bench.py default (--batch)"
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(detail, indent=1))
