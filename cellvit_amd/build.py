@@ -40,10 +40,10 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
     """ablation=True adds -DCVA_ABLATION (CVA_* experiment switches honoured; never used by bench.py / tests)."""
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
-    flags = FLAGS + (["-DCVA_ABLATION"] if ablation else [])
+    flags = FLAGS + (["-DCVA_ABLATION"] if ablation else []) + os.environ.get("CVA_BUILD_FLAGS", "").split()   # tuning experiments
     stamp = os.path.join(OBJ, ".flavour")
-    flavour = "ablation" if ablation else "production"
-    if not os.path.exists(stamp) or open(stamp).read().strip() != flavour:
+    flavour = ("ablation" if ablation else "production") + " " + os.environ.get("CVA_BUILD_FLAGS", "")
+    if not os.path.exists(stamp) or open(stamp).read().strip() != flavour.strip():
         force = True
         with open(stamp, "w") as f:
             f.write(flavour)
