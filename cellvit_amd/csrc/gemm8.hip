@@ -406,10 +406,12 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     // ---- per-tile state.  (m0, n0, swap) of the tile being computed / stored; the DMA row offsets and bases below
     // always describe the tile whose DMA is issued NEXT (they are advanced to tile t+1 before tile t's epilogue).
     const int lrow = lane >> 3, lpc = lane & 7;
-    auto a_bytes = [&](int m) {       // byte offset of activation row m
+    // Lane offsets of the DMA are 32-bit and relative to the TILE's first row (64-bit wave-uniform base per tile), so the
+    // operands themselves may be larger than 2 GiB (hidden activations of > 48 tiles at 1024^2).
+    auto a_row = [&](int m) -> long {     // physical activation row of logical row m
         long r = m;
         if (p.a_rpi > 0) r = (long)m + (long)(m / p.a_rpi) * p.a_extra + p.a_off;
-        return (unsigned)(r * (long)p.lda * ESZ);
+        return r;
     };
     unsigned a_voff[4], w_voff[4];
     const unsigned char* Ab;
@@ -437,16 +439,21 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             // TRANS: LDS row wc*64 + j*16 + g*4 + r of the "W" tile holds source row wc*64 + g*16 + j*4 + r, so that a
             // lane's 16 accumulator values per output row are 16 consecutive columns (see epilogue8_direct)
             const int prow = TRANS == 1 ? ((row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3)) : row;
+            const long ar0 = a_row(m0);
             if (!swap) {
-                a_voff[i] = a_bytes(m0 + row) + lp * 16;
-                w_voff[i] = (unsigned)((long)(n0 + prow) * p.ldw * ESZ) + lp * 16;
+                a_voff[i] = (unsigned)((a_row(m0 + row) - ar0) * (long)p.lda * ESZ) + lp * 16;
+                w_voff[i] = (unsigned)((long)prow * p.ldw * ESZ) + lp * 16;
             } else {
-                a_voff[i] = (unsigned)((long)(n0 + row) * p.ldw * ESZ) + lp * 16;
-                w_voff[i] = a_bytes(m0 + prow) + lp * 16;
+                a_voff[i] = (unsigned)((long)row * p.ldw * ESZ) + lp * 16;
+                w_voff[i] = (unsigned)((a_row(m0 + prow) - ar0) * (long)p.lda * ESZ) + lp * 16;
             }
         }
-        Ab = reinterpret_cast<const unsigned char*>(swap ? p.W : p.A);
-        Wb = reinterpret_cast<const unsigned char*>(swap ? p.A : p.W);
+        {
+            const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.A) + a_row(m0) * (long)p.lda * ESZ;
+            const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.W) + (long)n0 * p.ldw * ESZ;
+            Ab = swap ? wbase : abase;
+            Wb = swap ? abase : wbase;
+        }
         if (F8) {
             // scale images: activations  A-side layout p.a_scale (p.a_scale_w = W-side layout, for the swapped V tiles);
             //               weights      p.w_scale, packed per 256-row tile in the layout of the side the tile runs on
@@ -750,9 +757,8 @@ bool gemm8_supported(const GemmParams& p, int a_mode, size_t elem_size) {
     if (elem_size != 2 || a_mode != A_LINEAR || !p.epi_vec) return false;
     if (p.M % G8_BM || p.N % G8_BN || p.K % (2 * G8_BK) || p.K < 2 * G8_BK) return false;
     if (((size_t)p.A & 15) || ((size_t)p.W & 15) || (p.lda % 8) || (p.ldw % 8) || p.ldw < p.K) return false;
-    long max_arow = p.M - 1;
-    if (p.a_rpi > 0) max_arow = (long)(p.M - 1) + (long)((p.M - 1) / p.a_rpi) * p.a_extra + p.a_off;
-    if ((max_arow + 1) * (long)p.lda * 2 >= (1L << 31) || (long)p.N * p.ldw * 2 >= (1L << 31)) return false;
+    // (32-bit lane offsets are relative to a tile's first row: 256 rows, plus the few rows an a_rpi remap can insert)
+    if ((256L + (p.a_rpi > 0 ? (256L / p.a_rpi + 1) * p.a_extra : 0)) * p.lda * 2 >= (1L << 31) || 256L * p.ldw * 2 >= (1L << 31)) return false;
     if (p.out_mode == OUT_QKV && (p.D % G8_BN || p.hd % 16 || p.N != 3 * p.D || p.n_off)) return false;
     return true;
 }
@@ -762,7 +768,7 @@ bool gemm8_f8_supported(const GemmParams& p) {
     if (((size_t)p.A & 15) || ((size_t)p.W & 15) || (p.lda % 16) || (p.ldw % 16) || p.lda < p.K || p.ldw < p.K) return false;
     if (p.a_rpi || !p.a_scale || !p.w_scale) return false;
     if (((size_t)p.a_scale & 3) || ((size_t)p.w_scale & 3)) return false;
-    if ((long)p.M * p.lda >= (1L << 31) || (long)p.N * p.ldw >= (1L << 31)) return false;   // 32-bit lane offsets
+    if (256L * p.lda >= (1L << 31) || 256L * p.ldw >= (1L << 31)) return false;               // 32-bit lane offsets inside a tile
     if (p.out_mode == OUT_QKV && (p.D % G8_BN || p.hd % 16 || p.N != 3 * p.D || p.n_off || !p.a_scale_w)) return false;
     if (p.out_mode == OUT_MX8 && (!p.out || !p.out_scale || p.ldc % 16 || p.N % 128)) return false;
     if (p.out_mode == OUT_CONVT) return false;

@@ -149,3 +149,24 @@ def test_window_attention_persistent_many_items_and_race_screen():
         sl = slice(b * ntok, (b + 1) * ntok)
         ref = _attention_ref(xd[sl].float().cpu(), Wd.float().cpu(), bqkv, tab_h, tab_w, 1, gh, gw, 0, heads, D, win)
         assert _rel_err(outs[0][sl].float().cpu(), ref) < 1e-2
+
+
+def test_linear_8phase_operand_beyond_2_gib():
+    """A of 2.7 GB (fc2 of a 64-tile batch: M = 64 * 4096 rows of 5120 halves): lane offsets are relative to the tile's
+    first row, so the 8-phase kernel keeps serving batches past the old 2 GiB operand limit.  Row blocks from both ends
+    and the middle of the operand against torch."""
+    L, lib = _lib()
+    M, N, K = 64 * 4096, 256, 5120
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.empty((M, K), device="cuda", dtype=torch.float16)
+    for r0 in range(0, M, 32768):                              # fill in slabs (no fp32 temporary of the whole operand)
+        A[r0:r0 + 32768] = torch.randn((32768, K), device="cuda", generator=g).half()
+    W = (torch.randn((N, K), device="cuda", generator=g) / math.sqrt(K)).half()
+    b = torch.randn(N, device="cuda", generator=g) * 0.1
+    assert A.numel() * 2 > (1 << 31)
+    out = torch.empty((M, N), device="cuda", dtype=torch.float16)
+    L.check(lib.cv_op_linear(F16, _p(A), _p(W), _p(b), None, _p(out), 0, M, N, K, 0, None))
+    torch.cuda.synchronize()
+    for r0 in (0, 100000, 209715 // 256 * 256, M - 4096):
+        ref = F.linear(A[r0:r0 + 4096].float(), W.float(), b)
+        assert _rel_err(out[r0:r0 + 4096].float(), ref) < 2e-3, r0
