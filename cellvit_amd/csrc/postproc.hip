@@ -464,10 +464,10 @@ __global__ void k_marker_filter(int* __restrict__ marker, const int* __restrict_
 // marker-controlled watershed: one wave = one mask component, exact (value, age, index) order
 // ------------------------------------------------------------------------------------------------
 #ifndef CVA_POOL_LDS
-#define CVA_POOL_LDS 1024
+#define CVA_POOL_LDS 512
 #endif
 #ifndef CVA_BITMAP_WORDS
-#define CVA_BITMAP_WORDS 2048
+#define CVA_BITMAP_WORDS 1024
 #endif
 constexpr int POOL_LDS = CVA_POOL_LDS;             // frontier entries kept in LDS (20 B each); larger pools continue in the global arena
 constexpr int BITMAP_WORDS = CVA_BITMAP_WORDS;     // 32 * words pixels of bounding box keep their flood state in LDS
