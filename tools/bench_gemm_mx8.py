@@ -1,0 +1,59 @@
+"""Micro-benchmark of the MX-fp8 contraction entry point:  python tools/bench_gemm_mx8.py [M N K] [iters] [out_kind act]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from cellvit_amd import _lib  # noqa: E402
+
+
+def main():
+    M, N, K = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (131072, 5120, 1280)
+    iters = int(sys.argv[4]) if len(sys.argv) >= 5 else 20
+    out_kind = int(sys.argv[5]) if len(sys.argv) >= 6 else 0
+    act = int(sys.argv[6]) if len(sys.argv) >= 7 else 0
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    # random e4m3 bytes without the NaN encodings (0x7f / 0xff), scales 2^-2 .. 2^1
+    A = torch.randint(0, 256, (M, K), device="cuda", generator=g, dtype=torch.int16).to(torch.uint8)
+    W = torch.randint(0, 256, (N, K), device="cuda", generator=g, dtype=torch.int16).to(torch.uint8)
+    A[(A & 0x7f) == 0x7f] = 0x38
+    W[(W & 0x7f) == 0x7f] = 0x38
+    A &= 0xBF                                                    # |x| < 2: keeps sums finite in fp16 outputs
+    W &= 0xBF
+    sa = torch.randint(117, 121, (M * K // 32,), device="cuda", generator=g, dtype=torch.int16).to(torch.uint8)
+    sw = torch.randint(117, 121, (N * K // 32,), device="cuda", generator=g, dtype=torch.int16).to(torch.uint8)
+    b = torch.zeros(N, device="cuda")
+    res = torch.randn(M, N, device="cuda") if out_kind == 1 else None
+    out = torch.empty((M, N), device="cuda", dtype=[torch.float16, torch.float32, torch.uint8][out_kind])
+    osc = torch.zeros((M * N // 32,), device="cuda", dtype=torch.uint8) if out_kind == 2 else None
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+
+    def run():
+        return lib.cv_op_linear_mx8(p(A), p(sa), None, p(W), p(sw), p(b), p(res), p(out), out_kind, p(osc), M, N, K, act, None)
+    for _ in range(3):
+        _lib.check(run())
+    torch.cuda.synchronize()
+    first = out.clone()
+    bad = 0
+    for _ in range(int(os.environ.get("RACE", "4"))):
+        out.zero_()
+        run()
+        torch.cuda.synchronize()
+        bad += int((out != first).sum().item())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"mx8 M={M} N={N} K={K} out_kind={out_kind} act={act}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s"
+          + (f"  RACE: {bad} mismatching elements" if bad else "  (repeat launches bit-identical)"))
+
+
+if __name__ == "__main__":
+    main()
