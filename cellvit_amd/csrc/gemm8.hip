@@ -58,13 +58,6 @@ namespace {
 using namespace epi;
 
 constexpr int G8_BM = 256, G8_BN = 256, G8_BK = 64, G8_NT = 512;
-#ifndef CVA_G8_SPLIT
-#define CVA_G8_SPLIT 1
-#endif
-// 1: balanced DMA issue — two global_load_lds per wave in EVERY phase (a tile's A / W stage split in halves) instead of four in
-// phases 3, 4, 7, 8 and none in the others: a phase's pre-barrier segment (fragment reads + DMA issue) then stays close to the
-// 256 cycles the partner wave group's MFMAs take, where the 4-piece phases ran ~600 cycles.  0: the round-1 schedule (A/B).
-constexpr bool G8_SPLIT = CVA_G8_SPLIT != 0;
 constexpr int G8_TILE = 256 * 128;          // bytes of one A or W tile (256 rows x 128 B)
 constexpr int G8_WOFF = 2 * G8_TILE;        // LDS layout: [E.A][O.A][E.W][O.W] -> buffer select = +32 KiB immediate offset
 constexpr int G8_BIAS = 4 * G8_TILE;       // two 1-KiB bias slots (256 floats each, alternating per output tile)
@@ -482,24 +475,22 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 #define G8_DMA4(voff, base, ldsaddr)                                                                        \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), \
                  "s"(ldsaddr) : "memory")
-    // `half`: -1 = the whole tile (4 pieces per wave), 0 / 1 = pieces {0, 1} / {2, 3}: the balanced schedule (G8_SPLIT) issues two
-    // DMA instructions per phase instead of four in half of the phases
-    auto stage_a = [&](int buf, int kt, int half = -1) {
-        if (F8 && half <= 0) {      // the K tile's scale blocks first (oldest load of the stage: every counted wait that covers the tile covers them)
+    auto stage_a = [&](int buf, int kt) {
+        if (F8) {      // the K tile's scale blocks first (oldest load of the stage: every counted wait that covers the tile covers them)
             const unsigned char* sbase = uniform_ptr(Sb + (long)(kstart + kt * kstep) * 1024);
             const unsigned sdst = __builtin_amdgcn_readfirstlane(lds0 + G8_SC + buf * 2048 + wave * 256);
             G8_DMA4(sc_voff, sbase, sdst);
         }
         const unsigned char* base = uniform_ptr(Ab + (long)(kstart + kt * kstep) * (G8_BK * 2));
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G8_TILE + wave * 4096);
-        if (half <= 0) { G8_DMA(a_voff[0], base, dst); G8_DMA(a_voff[1], base, dst + 1024); }
-        if (half != 0) { G8_DMA(a_voff[2], base, dst + 2048); G8_DMA(a_voff[3], base, dst + 3072); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) G8_DMA(a_voff[i], base, dst + i * 1024);
     };
-    auto stage_w = [&](int buf, int kt, int half = -1) {
+    auto stage_w = [&](int buf, int kt) {
         const unsigned char* base = uniform_ptr(Wb + (long)(kstart + kt * kstep) * (G8_BK * 2));
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + G8_WOFF + buf * G8_TILE + wave * 4096);
-        if (half <= 0) { G8_DMA(w_voff[0], base, dst); G8_DMA(w_voff[1], base, dst + 1024); }
-        if (half != 0) { G8_DMA(w_voff[2], base, dst + 2048); G8_DMA(w_voff[3], base, dst + 3072); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) G8_DMA(w_voff[i], base, dst + i * 1024);
     };
 
     // ---- fragment read offsets: row r (r & 15 == lane & 15), logical piece ks*4 + g -> byte r*128 + ((lp ^ ((r>>1)&7)) << 4)
@@ -576,12 +567,8 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         }
         stage_a(0, 0);
         stage_w(0, 0);
-        if (G8_SPLIT) {              // the rest of O is staged by the first phases of the K loop, as in every iteration
-            if (F8) stage_w(1, 1, 0); else stage_w(1, 1);
-        } else {
-            stage_w(1, 1);
-            if (!F8) stage_a(1, 1);  // (fp8 schedule: O.A is staged in phase 1 of every iteration, the first included)
-        }
+        stage_w(1, 1);
+        if (!F8) stage_a(1, 1);      // (fp8 schedule: O.A is staged in phase 1 of every iteration, the first included)
     };
 
     // ---- persistent loop over output tiles: the DMA of tile t+1's first two K tiles is issued BEFORE tile t's
@@ -619,39 +606,6 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             //   (the prologue of an output tile stages E.A, E.W and O.W: phase 1 is the same in every iteration)
             // WAR (re-stage >= 2 phases after the last read): E.W 2 -> 4, E.A 3 -> 5, O.W 6 -> 8, O.A 7 -> 1'; the scale images
             // travel with the A stages (E: last read 3 -> 5, O: 7 -> 1').  RAW (read >= 1 phase after the retiring wait): O 4 -> 5, E 8 -> 1'.
-            if (G8_SPLIT) {
-                // balanced issue (two DMA per phase; the scale dword rides with the first half of an A stage):
-                //   ph 1: O.W hi   2: O.A lo   3: O.A hi   4: E.W' lo + vmcnt(2): O complete   5: E.W' hi   6: E.A' lo   7: E.A' hi
-                //   ph 8: O.W' lo + vmcnt(2): E' complete            (X' = tile kt+2 / kt+3; WAR / RAW distances as in the table above)
-                G8_VMCNT(2);                        // E (tile + scales) has landed; O.W lo may still be in flight
-                G8_BAR8();
-                if (wr == 1) G8_BAR8();
-                for (int kt = 0; kt < nk; kt += 2) {
-                    const bool more = kt + 2 < nk;
-                    G8F_RD_A(F0, sA0, 0, 0); G8F_RD_W(FX, 0, 0); G8F_RD_SW(sWE, 0);
-                    stage_w(1, kt + 1, 1);
-                    G8_BAR8(); G8_MMQ8(F0, FX, sA0, sWE, 0, 0); G8_BAR8();
-                    G8F_RD_W(FY, 0, 1);
-                    stage_a(1, kt + 1, 0);
-                    G8_BAR8(); G8_MMQ8(F0, FY, sA0, sWE, 0, 1); G8_BAR8();
-                    G8F_RD_A(F1, sA1, 0, 1);
-                    stage_a(1, kt + 1, 1);
-                    G8_BAR8(); G8_MMQ8(F1, FY, sA1, sWE, 1, 1); G8_BAR8();
-                    if (more) { stage_w(0, kt + 2, 0); G8_VMCNT(2); } else { G8_VMCNT(0); }
-                    G8_BAR8(); G8_MMQ8(F1, FX, sA1, sWE, 1, 0); G8_BAR8();
-                    G8F_RD_A(F0, sA0, 1, 0); G8F_RD_W(FY, 1, 0); G8F_RD_SW(sWO, 1);
-                    if (more) stage_w(0, kt + 2, 1);
-                    G8_BAR8(); G8_MMQ8(F0, FY, sA0, sWO, 0, 0); G8_BAR8();
-                    G8F_RD_W(FX, 1, 1);
-                    if (more) stage_a(0, kt + 2, 0);
-                    G8_BAR8(); G8_MMQ8(F0, FX, sA0, sWO, 0, 1); G8_BAR8();
-                    G8F_RD_A(F1, sA1, 1, 1);
-                    if (more) stage_a(0, kt + 2, 1);
-                    G8_BAR8(); G8_MMQ8(F1, FX, sA1, sWO, 1, 1); G8_BAR8();
-                    if (more) { stage_w(1, kt + 3, 0); G8_VMCNT(2); }
-                    G8_BAR8(); G8_MMQ8(F1, FY, sA1, sWO, 1, 0); G8_BAR8();
-                }
-            } else {
             G8_VMCNT(4);                            // E (tile + its scale blocks) has landed; O.W may still be in flight
             G8_BAR8();
             if (wr == 1) G8_BAR8();                 // stagger the second wave group by one barrier
@@ -683,42 +637,6 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
                 // ---- phase 8
                 if (more) { stage_w(1, kt + 3); G8_VMCNT(4); }
                 G8_BAR8(); G8_MMQ8(F1, FY, sA1, sWO, 1, 0); G8_BAR8();
-            }
-            }
-        } else {
-        if (G8_SPLIT && !no_dma) {
-            // balanced issue, two DMA per phase (reads stay one phase ahead as in the table of the file header):
-            //   ph 1: O.A lo   2: O.A hi   3: E.W' lo + vmcnt(2): O complete   4: E.W' hi   5: E.A' lo   6: E.A' hi
-            //   ph 7: O.W' lo + vmcnt(2): E' complete   8: O.W' hi
-            // WAR (re-stage >= 2 phases after the last read): E.W 1 -> 3, E.A 2 -> 5, O.W 5 -> 7, O.A 6 -> 1'; RAW: O 3 -> 4, E' 7 -> 8.
-            G8_VMCNT(4);                            // E has landed (O.W may still be in flight)
-            G8_BAR();
-            if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }
-            if (wr == 1) G8_BAR();
-            for (int kt = 0; kt < nk; kt += 2) {
-                const bool more = kt + 2 < nk;
-                if (!no_rd) G8_RD_W(Y, 0, 1);
-                stage_a(1, kt + 1, 0);
-                G8_BAR(); G8_MMQ(4, A0, X, 0, 0); G8_BAR();
-                if (!no_rd) G8_RD_A(A1, 0, 1);
-                stage_a(1, kt + 1, 1);
-                G8_BAR(); G8_MMQ(8, A0, Y, 0, 1); G8_BAR();
-                if (more) { stage_w(0, kt + 2, 0); G8_VMCNT(2); } else { G8_VMCNT(0); }
-                G8_BAR(); G8_MMQ(0, A1, Y, 1, 1); G8_BAR();
-                if (!no_rd) { G8_RD_A(A0, 1, 0); G8_RD_W(Y, 1, 0); }
-                if (more) stage_w(0, kt + 2, 1);
-                G8_BAR(); G8_MMQ(12, A1, X, 1, 0); G8_BAR();
-                if (!no_rd) G8_RD_W(X, 1, 1);
-                if (more) stage_a(0, kt + 2, 0);
-                G8_BAR(); G8_MMQ(4, A0, Y, 0, 0); G8_BAR();
-                if (!no_rd) G8_RD_A(A1, 1, 1);
-                if (more) stage_a(0, kt + 2, 1);
-                G8_BAR(); G8_MMQ(8, A0, X, 0, 1); G8_BAR();
-                if (more) { stage_w(1, kt + 3, 0); G8_VMCNT(2); }
-                G8_BAR(); G8_MMQ(0, A1, X, 1, 1); G8_BAR();
-                if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }
-                if (more) stage_w(1, kt + 3, 1);
-                G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
             }
         } else {
         G8_VMCNT(8);                                // E has landed (O may still be in flight); older epilogue stores have drained
@@ -754,7 +672,6 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }     // (after the last tile: a harmless read of stale data)
             if (more && !no_dma) stage_a(1, kt + 3);
             G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
-        }
         }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
