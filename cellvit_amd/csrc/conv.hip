@@ -37,16 +37,7 @@ __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
 // ABL (ablation builds only, CVA_CONV_DBG): 1 = stage the filter taps of the first chunk only, 2 = the halo of the first
 // chunk only, 4 = no MFMAs — timing experiments, results are wrong by construction.
-// PP = 1: wave-group ping-pong as in gemm8.hip.  A tap is a phase { issue the NEXT tap's fragment reads; barrier; counted wait;
-// 16 MFMAs at raised priority; barrier } and waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave's LDS reads
-// coincide with the other wave's MFMAs.  (Ablations of the lock-step kernel on a deep layer added up without any overlap:
-// MFMA 626 + LDS reads / skeleton 341 + DMA 214 = 1181 us.)  Chunk boundary under the stagger: every wave retires its DMA share
-// (vmcnt(0)) before the last tap's second barrier and one extra barrier follows, so the trailing group's wait precedes the
-// leading group's first read of the new chunk; the buffer a chunk's DMA overwrites was last read two barriers earlier.
-#ifndef CVA_CONV_PP
-#define CVA_CONV_PP 1
-#endif
-template <int MINW, int ABL = 0, int PP = CVA_CONV_PP>
+template <int MINW, int ABL = 0>
 __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParams p) {
     using TR = Traits<half_t>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -182,41 +173,6 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (PP) {
-#define CV_BAR()                                   \
-    do {                                           \
-        __builtin_amdgcn_sched_barrier(0);         \
-        __builtin_amdgcn_s_barrier();              \
-        __builtin_amdgcn_sched_barrier(0);         \
-    } while (0)
-// one tap = one phase; reads of the next tap go out before the first barrier
-#define CV_PHASE(TAP, bbase, LASTWAIT)                                                                          \
-    do {                                                                                                        \
-        if ((TAP) < 8) CV_READ_TAP((TAP) + 1, ((TAP) + 1) & 1, bbase);                                          \
-        CV_BAR();                                                                                               \
-        if ((TAP) < 8) CV_WAIT(8, (TAP) & 1); else CV_WAIT(0, (TAP) & 1);                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        __builtin_amdgcn_s_setprio(1);                                                                          \
-        CV_MMA_TAP((TAP) & 1);                                                                                  \
-        __builtin_amdgcn_s_setprio(0);                                                                          \
-        if (LASTWAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
-        CV_BAR();                                                                                               \
-    } while (0)
-        const bool late = wave >= NWAVE / 2;             // waves 4-7: the trailing group
-        if (late) CV_BAR();
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int buf = ch & 1;
-            const unsigned bbase = buf * CONV_LDS;
-            CV_READ_TAP(0, 0, bbase);
-            if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            CV_PHASE(0, bbase, false); CV_PHASE(1, bbase, false); CV_PHASE(2, bbase, false);
-            CV_PHASE(3, bbase, false); CV_PHASE(4, bbase, false); CV_PHASE(5, bbase, false);
-            CV_PHASE(6, bbase, false); CV_PHASE(7, bbase, false); CV_PHASE(8, bbase, true);
-            CV_BAR();
-        }
-        if (!late) CV_BAR();                             // realign the groups: every LDS read has retired
-    } else {
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         const unsigned bbase = buf * CONV_LDS;
@@ -228,7 +184,6 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
         CV_STEP(6, bbase); CV_STEP(7, bbase); CV_STEP(8, bbase);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-    }
     }
     __syncthreads();
 
