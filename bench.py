@@ -7,7 +7,7 @@
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment launches those N ranks itself (re-exec under
 torch.distributed.run on 127.0.0.1), one process per GPU over RCCL.
 
-One *step* = one batch of B (default 32) synthetic 1024x1024 tiles through the whole hot path:
+One *step* = one batch of B (default 64) synthetic 1024x1024 tiles through the whole hot path:
   raw uint8 tiles -> inference transform fused into the forward's loaders (cv_forward_u8) -> forward (ViT encoder +
   shared skips + 3 decoder branches, HIP)  ->  on-device Sobel / marker watershed post-processing up to the per-tile
   instance records (HIP).
@@ -46,10 +46,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32,
+    ap.add_argument("--batch", type=int, default=64,
                     help="tiles per step per GPU (the reference CLI default batch_size is 8; multiples of 16 make the token count a\n"
                          "multiple of 256 row tiles = one per CU, so every linear layer tiles the chip without a partial round;\n"
-                         "32 measured +1.8 %% over 16 in one run: fewer per-launch tails, post-processing tail amortised)")
+                         "same-box A/B: 16 -> 32 +1.8 %%, 32 -> 48 +1.4 %%, 32 -> 64 +1.6 %% (fewer per-launch tails); 64 tiles need ~90 GB of the 288 GB)")
     ap.add_argument("--model", default="samh", choices=["samh", "vit256"])
     ap.add_argument("--tile", type=int, default=1024)
     ap.add_argument("--cells", type=int, default=800, help="synthetic nuclei per 1024^2 tile (post-proc input)")

@@ -149,17 +149,24 @@ __global__ void k_comp_stats(const int* __restrict__ Lb, int* __restrict__ csize
     }
 }
 
-// blb = fg && size >= 10 (hard-wired, post_proc:182); surviving roots are queued for the flood
+// blb = fg && size >= 10 (hard-wired, post_proc:182); surviving roots are queued for the flood.  The flood of a component is a
+// sequential chain (one pop per pixel), so the batch ends when the LARGEST components end: components of >= FLOOD_BIG pixels go to the
+// front of the tile's list (filled from slot 0 up), the rest to the back (filled from the last slot down), and the flood's waves are
+// dispatched tile-interleaved — every tile's long chains start in the first moments (longest-processing-time-first, approximately).
+// The order in which components are flooded has no influence on the result (they do not interact).
+constexpr int FLOOD_BIG = 1024;
 __global__ void k_blb_finalize(const int* __restrict__ Lb, const int* __restrict__ csize, uint8_t* __restrict__ blb,
-                               int* __restrict__ comp_list, int* __restrict__ comp_count, int N, int list_cap) {
+                               int* __restrict__ comp_list, int* __restrict__ small_count, int* __restrict__ big_count, int N,
+                               int list_cap) {
     const long base = (long)blockIdx.y * N;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         const int r = Lb[base + i];
-        const bool keep = r >= 0 && csize[base + r] >= 10;
+        const int sz = r >= 0 ? csize[base + r] : 0;
+        const bool keep = sz >= 10;
         blb[base + i] = keep ? 1 : 0;
-        if (keep && r == i) {
-            const int slot = atomicAdd(&comp_count[blockIdx.y], 1);
-            if (slot < list_cap) comp_list[(long)blockIdx.y * list_cap + slot] = i;
+        if (keep && r == i) {                         // (>= 10 pixels per component: at most N / 10 entries, list_cap = N / 10 + 16)
+            if (sz >= FLOOD_BIG) comp_list[(long)blockIdx.y * list_cap + atomicAdd(&big_count[blockIdx.y], 1)] = i;
+            else comp_list[(long)blockIdx.y * list_cap + (list_cap - 1 - atomicAdd(&small_count[blockIdx.y], 1))] = i;
         }
     }
 }
@@ -476,7 +483,7 @@ typedef unsigned long long u64;
 struct FloodParams {
     const double* dist; const uint8_t* blb; int* inst;       // [B][N]
     const int* root1; const int* bb; const int* csize;      // component labels, bboxes, pixel counts of the mask
-    const int* comp_list; const int* comp_count; int list_cap;
+    const int* comp_list; const int* comp_count; const int* big_count; int list_cap;   // comp_count = the small ones (from the back)
     int* queue_head;                                          // [B] dequeue cursors
     u64* ovf_hi; u64* ovf_lo; int* ovf_lab; u64* ovf_cursor;  // overflow arena [B][N]
     int H, W, B;
@@ -533,21 +540,22 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
     const int lane = threadIdx.x;
     const int N = p.H * p.W, W = p.W, H = p.H;
     {
-        const int tile = blockIdx.y;
+        const int tile = blockIdx.x;                // tile-interleaved dispatch: wave slot blockIdx.y of every tile before slot + 1 of any
         const long base = (long)tile * N;
         const double* dist = p.dist + base;
         int* inst = p.inst + base;
         const int* root1 = p.root1 + base;
         const int* y0a = p.bb + base * 4; const int* y1a = y0a + N; const int* x0a = y1a + N; const int* x1a = x0a + N;
         u64* ohi = p.ovf_hi + base; u64* olo = p.ovf_lo + base; int* olab = p.ovf_lab + base;
-        int ncomp = p.comp_count[tile];
+        const int nbig = p.big_count[tile];
+        int ncomp = nbig + p.comp_count[tile];
         if (ncomp > p.list_cap) ncomp = p.list_cap;
         for (;;) {
             int ci = 0;
             if (lane == 0) ci = atomicAdd(&p.queue_head[tile], 1);
             ci = __shfl(ci, 0);
             if (ci >= ncomp) break;
-            const int root = p.comp_list[(long)tile * p.list_cap + ci];
+            const int root = p.comp_list[(long)tile * p.list_cap + (ci < nbig ? ci : p.list_cap - 1 - (ci - nbig))];
             const int by0 = y0a[root], by1 = y1a[root], bx0 = x0a[root], bx1 = x1a[root];
             const int bw = bx1 - bx0 + 1, barea = bw * (by1 - by0 + 1);
             const int carea = p.csize[base + root];   // pool entries never exceed the component's pixel count
@@ -967,7 +975,8 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     hipLaunchKernelGGL(k_comp_stats, grid, blk, 0, st, w->L1, w->csize, w->bb, H, W);
     int* comp_count = w->counters;            // [B]
     int* queue_head = w->counters + B;        // [B]
-    hipLaunchKernelGGL(k_blb_finalize, grid, blk, 0, st, w->L1, w->csize, w->blb, w->comp_list, comp_count, N, w->list_cap);
+    int* big_count = w->counters + 3 * B;     // [B]
+    hipLaunchKernelGGL(k_blb_finalize, grid, blk, 0, st, w->L1, w->csize, w->blb, w->comp_list, comp_count, big_count, N, w->list_cap);
     // ---- P2/P3: min-max normalise (fused) + separable Sobel in fp64 ----
     hipLaunchKernelGGL((k_minmax_partial<float>), dim3(RED_BLOCKS, 2, B), blk, 0, st, hv, 2, N, w->partial);
     hipLaunchKernelGGL(k_minmax_final, dim3(2, B), blk, 0, st, w->partial, 2, w->params_hv);
@@ -995,11 +1004,11 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     // ---- P6: ordered flood ----
     FloodParams fp{};
     fp.dist = w->dist; fp.blb = w->blb; fp.inst = inst_out; fp.root1 = w->L1; fp.bb = w->bb; fp.csize = w->csize;
-    fp.comp_list = w->comp_list; fp.comp_count = comp_count; fp.list_cap = w->list_cap; fp.queue_head = queue_head;
+    fp.comp_list = w->comp_list; fp.comp_count = comp_count; fp.big_count = big_count; fp.list_cap = w->list_cap; fp.queue_head = queue_head;
     fp.ovf_hi = reinterpret_cast<unsigned long long*>(w->ovf_v); fp.ovf_lo = w->ovf_lo; fp.ovf_lab = w->ovf_lab; fp.ovf_cursor = w->ovf_cursor;
     fp.H = H; fp.W = W; fp.B = B;
     { static const int dbg = cva_env_int("CVA_PP_DBG", 0); fp.dbg = dbg; }   // ablation builds only (common.h)
-    hipLaunchKernelGGL(k_flood, dim3(1024, B), dim3(64), 0, st, fp);
+    hipLaunchKernelGGL(k_flood, dim3(B, 1024), dim3(64), 0, st, fp);
     // ---- P7/P8: per-instance records + contours ----
     hipLaunchKernelGGL(k_inst_stats, grid, blk, 0, st, inst_out, type, w->st, H, W, d.max_ids, nr_types);
     hipLaunchKernelGGL(k_inst_records, dim3(B), blk, 0, st, w->st, recs, n_recs, d.max_ids, d.max_inst, nr_types, nmark);
