@@ -228,6 +228,18 @@ def main():
     e[2].record()
     torch.cuda.synchronize()
     fwd_ms, pp_ms = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+    # the product hand-off at full size, outside the timed region: post-processing of the forward's OWN argmax planes / HV map
+    # (random-weight outputs: salt and pepper, hence not the workload — it shows the route forward -> planes -> watershed runs)
+    handoff_ms = None
+    if do_pp:
+        o2 = model.forward_u8(x, MEAN, STD)
+        h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        h0.record()
+        r2 = postprocess_device(*model._last_argmax, o2["hv_map"], 6, 10, 21, want_contours=True)
+        h1.record()
+        torch.cuda.synchronize()
+        handoff_ms = {"postproc_on_forward_outputs_ms": h0.elapsed_time(h1), "instances": int(r2[2].sum().item())}
+        del o2, r2
 
     eng = model._last_engine
     kernel_events = not args.no_kernel_events
@@ -289,6 +301,7 @@ def main():
                        "postproc": bool(do_pp), "postproc_stream_overlap": bool(overlap), "postproc_input": f"synthetic nuclei maps, {args.cells} cells/tile",
                        "instances_per_step": n_inst},
             "stage_ms_sequential": {"forward": fwd_ms, "postproc": pp_ms},
+            "handoff_check": handoff_ms,
             # forward time at 100 % of the MFMA peak(s) / measured forward time.  f8: the qkv / fc1 / fc2 share of the algorithmic
             # FLOPs (11/12 of the encoder's 5.154 TFLOP of linear layers per 1024^2 SAM-H tile) is priced at the MX-fp8 peak
             "whole_forward_mfma_frac": (B * (flops_per_tile / (MFMA_F16_PEAK_TFLOPS * 1e12)) / (fwd_ms * 1e-3)) if args.dtype == "f16" or args.model != "samh"
