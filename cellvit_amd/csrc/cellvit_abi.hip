@@ -1245,6 +1245,17 @@ extern "C" int cv_pp_run(cv_pp* p, const uint8_t* bin, const uint8_t* type, cons
     return cv_pp_run_params(p, bin, type, hv, B, object_size, ksize, nr_types, inst_map, recs, n_recs, contours, n_pts, stream);
 }
 
+extern "C" int cv_pp_records(cv_pp* p, int32_t* inst_map, const uint8_t* type, int B, int nr_types, cv_instance* recs,
+                             int32_t* n_recs, int32_t* contours, int32_t* n_pts, void* stream) {
+    if (!p || !inst_map || !recs || !n_recs || !n_pts) { cva_set_error("null argument"); return CV_ERR_INVALID; }
+    if (nr_types < 0 || nr_types > 8 || (nr_types > 0 && !type)) { cva_set_error("nr_types must be in [0, 8]"); return CV_ERR_INVALID; }
+    if (B <= 0 || B > p->d.B) { cva_set_error("batch %d exceeds the handle's max_batch %d", B, p->d.B); return CV_ERR_INVALID; }
+    const int rc = pp_records(p->ws, inst_map, type, B, nr_types, reinterpret_cast<InstanceRec*>(recs), n_recs, contours, n_pts,
+                              reinterpret_cast<hipStream_t>(stream));
+    if (rc) { cva_set_error("instance-record launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError())); return CV_ERR_HIP; }
+    return CV_OK;
+}
+
 extern "C" int cv_pp_debug_read(cv_pp* p, const char* name, void* host_dst, size_t bytes) {
     if (!p || !name || !host_dst || p->last_B <= 0) { cva_set_error("nothing to read"); return CV_ERR_STATE; }
     const size_t n = (size_t)p->last_B * p->d.H * p->d.W;

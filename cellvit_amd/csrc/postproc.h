@@ -36,6 +36,10 @@ int pp_run(PostprocWorkspace* ws, const uint8_t* bin, const uint8_t* type, const
            int ksize, int nr_types, int32_t* inst_out, InstanceRec* recs, int32_t* n_recs, int32_t* contours,
            int32_t* n_pts, hipStream_t stream);
 
+// Records + contours of caller-supplied instance maps (i32 [B,H,W], modified in place: negative ids -> 0), the P7/P8 tail only.
+int pp_records(PostprocWorkspace* ws, int32_t* inst_io, const uint8_t* type, int B, int nr_types, InstanceRec* recs,
+               int32_t* n_recs, int32_t* contours, int32_t* n_pts, hipStream_t stream);
+
 // debug taps of the last run (device pointers, valid until the next run)
 const int32_t* pp_dbg_blb(const PostprocWorkspace* ws);     // u8 promoted? no: int32 not stored; see .hip
 const double* pp_dbg_dist(const PostprocWorkspace* ws);

@@ -1020,4 +1020,31 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     return (int)hipGetLastError();
 }
 
+__global__ void k_fill_counts(int* __restrict__ dst, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
+// Records + contours of GIVEN instance maps (post_proc_cellvit.py:252-330, `calculate_instances`, the ground-truth side of
+// the evaluation callers): the P7/P8 tail of pp_run on caller-supplied ids.  Ids above max_ids have no accumulator
+// slot and are not reported; ids <= 0 are background (negative ones are zeroed in place like pp_run does).
+int pp_records(PostprocWorkspace* w, int32_t* inst_io, const uint8_t* type, int B, int nr_types, InstanceRec* recs,
+               int32_t* n_recs, int32_t* contours, int32_t* n_pts, hipStream_t st) {
+    const PostprocDims& d = w->d;
+    if (B > d.B || B <= 0) return 1;
+    const int H = d.H, W = d.W, N = H * W;
+    const dim3 grid(std::min((N + NT - 1) / NT, 2048), B), blk(NT);
+    int* nmark = w->counters + 2 * B;         // [B]: here simply "every id slot may be live"
+    hipLaunchKernelGGL(k_fill_counts, dim3((B + NT - 1) / NT), blk, 0, st, nmark, B, d.max_ids);
+    hipLaunchKernelGGL(k_stats_init, dim3(std::min((d.max_ids + NT) / NT, 32), B), blk, 0, st, w->st, w->msize, nmark, d.max_ids);
+    hipLaunchKernelGGL(k_inst_stats, grid, blk, 0, st, inst_io, type, w->st, H, W, d.max_ids, nr_types);
+    hipLaunchKernelGGL(k_inst_records, dim3(B), blk, 0, st, w->st, recs, n_recs, d.max_ids, d.max_inst, nr_types, nmark);
+    const dim3 cgrid((d.max_inst + 63) / 64 > 64 ? 64 : (d.max_inst + 63) / 64, B);
+    hipLaunchKernelGGL(k_contour_count, cgrid, dim3(64), 0, st, inst_io, recs, n_recs, H, W, d.max_inst);
+    hipLaunchKernelGGL(k_contour_offsets, dim3(B), blk, 0, st, recs, n_recs, n_pts, d.max_inst);
+    if (contours)
+        hipLaunchKernelGGL(k_contour_write, cgrid, dim3(64), 0, st, inst_io, recs, n_recs, contours, H, W, d.max_inst, d.max_pts);
+    return (int)hipGetLastError();
+}
+
 }  // namespace cva

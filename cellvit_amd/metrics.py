@@ -5,7 +5,11 @@ Restates the behaviour of the reference's panoptic quality (`cell_segmentation/u
 `get_fast_pq` / `remap_label`) with a different mechanism: instead of materialising one mask per instance, the
 pairwise intersections come from ONE joint histogram of (true id, pred id) pairs, so the cost is O(pixels) rather
 than O(instances x pixels).  Pinned to outputs of the imported reference in `tests/golden/pq_cases.npz`
-(`tools/make_golden_pq.py`).
+(`tools/make_golden_pq.py`) and, for `binarize` and the detection scores, `tests/golden/eval_cases.npz`
+(`tools/make_golden_eval.py`).  `binary_dice` / `binary_jaccard` restate the torchmetrics calls of the evaluation caller
+(torchmetrics is not installed here: parity unpinned, the formulas are the library's documented ones);
+`pair_coordinates` is the reference's scipy call sequence (its module needs numba to import, so it is pinned by an
+exhaustive-assignment property test instead).
 """
 from __future__ import annotations
 
@@ -76,3 +80,75 @@ def binary_pq_batch(true_maps: List[np.ndarray], pred_maps: List[np.ndarray]) ->
     `inference_cellvit_experiment_pannuke.py:650-660`)."""
     vals = [panoptic_quality(remap_label(t), remap_label(p))[0][2] for t, p in zip(true_maps, pred_maps)]
     return float(np.mean(vals)) if vals else 0.0
+
+
+def binarize(x: np.ndarray) -> np.ndarray:
+    """Per-class instance maps [H, W, C] -> one instance map with ids 1..n in (channel, ascending id) order; where
+    instances of different channels overlap the later one wins (reference `metrics.py:190-211`, which multiplies the
+    running map by the complement of every instance mask; here one lookup per channel)."""
+    x = np.asarray(x)
+    out = np.zeros(x.shape[:2], dtype=np.int64)
+    count = 0
+    for c in range(x.shape[2]):
+        ids, inv = np.unique(x[:, :, c], return_inverse=True)
+        inv = inv.reshape(x.shape[:2])
+        fg = ids != 0
+        rank = np.cumsum(fg) * fg                        # 1..k for the non-zero ids in ascending order, 0 for id 0
+        lab = rank[inv]
+        out = np.where(lab > 0, lab + count, out)
+        count += int(fg.sum())
+    return out.astype("int32")
+
+
+def pair_coordinates(set_a: np.ndarray, set_b: np.ndarray, radius: float):
+    """Minimum-total-distance unique pairing of two point sets, pairs farther apart than `radius` discarded
+    (reference `utils/tools.py:104-147`): (pairing [k, 2] of (index in A, index in B), unpaired A, unpaired B)."""
+    from scipy.optimize import linear_sum_assignment
+    from scipy.spatial.distance import cdist
+    cost = cdist(set_a, set_b, metric="euclidean")
+    ia, ib = linear_sum_assignment(cost)
+    keep = cost[ia, ib] <= radius
+    pa, pb = ia[keep], ib[keep]
+    pairing = np.concatenate([pa[:, None], pb[:, None]], axis=-1)
+    return pairing, np.delete(np.arange(set_a.shape[0]), pa), np.delete(np.arange(set_b.shape[0]), pb)
+
+
+def cell_detection_scores(paired_true, paired_pred, unpaired_true, unpaired_pred, w=(1, 1)):
+    """(f1, precision, recall) of the detection task from the pairing (reference `metrics.py:221-236`)."""
+    tp, fp, fn = paired_pred.shape[0], unpaired_pred.shape[0], unpaired_true.shape[0]
+    return 2 * tp / (2 * tp + w[0] * fp + w[1] * fn), tp / (tp + fp), tp / (tp + fn)
+
+
+def cell_type_detection_scores(paired_true, paired_pred, unpaired_true, unpaired_pred, type_id, w=(2, 2, 1, 1),
+                               exhaustive: bool = True):
+    """(f1, precision, recall) of one nucleus type (reference `metrics.py:239-274`)."""
+    sel = (paired_true == type_id) | (paired_pred == type_id)
+    pt, pp = paired_true[sel], paired_pred[sel]
+    tp = ((pt == type_id) & (pp == type_id)).sum()
+    tn = ((pt != type_id) & (pp != type_id)).sum()
+    fp = ((pt != type_id) & (pp == type_id)).sum()
+    fn = ((pt == type_id) & (pp != type_id)).sum()
+    if not exhaustive:
+        fp -= (pt == -1).sum()
+    fp_d, fn_d = (unpaired_pred == type_id).sum(), (unpaired_true == type_id).sum()
+    prec = (tp + tn) / (tp + tn + w[0] * fp + w[2] * fp_d)
+    rec = (tp + tn) / (tp + tn + w[1] * fn + w[3] * fn_d)
+    f1 = (2 * (tp + tn)) / (2 * (tp + tn) + w[0] * fp + w[1] * fn + w[2] * fp_d + w[3] * fn_d)
+    return f1, prec, rec
+
+
+def binary_dice(pred: np.ndarray, target: np.ndarray) -> float:
+    """torchmetrics.functional.dice(preds, target, ignore_index=0) on {0, 1} maps (caller :817-822): the micro dice of
+    the foreground class, 2 tp / (2 tp + fp + fn), 0 when the denominator is 0."""
+    p, t = np.asarray(pred) > 0, np.asarray(target) > 0
+    tp, fp, fn = int((p & t).sum()), int((p & ~t).sum()), int((~p & t).sum())
+    den = 2 * tp + fp + fn
+    return 2.0 * tp / den if den else 0.0
+
+
+def binary_jaccard(pred: np.ndarray, target: np.ndarray) -> float:
+    """torchmetrics.functional.classification.binary_jaccard_index (caller :826-833): tp / (tp + fp + fn), 0 when empty."""
+    p, t = np.asarray(pred) > 0, np.asarray(target) > 0
+    tp, fp, fn = int((p & t).sum()), int((p & ~t).sum()), int((~p & t).sum())
+    den = tp + fp + fn
+    return float(tp) / den if den else 0.0

@@ -4,6 +4,7 @@ Reference surface reproduced (same names / argument meaning / error behaviour):
   * ``DetectionCellPostProcessor(nr_types, magnification, gt).post_process_cell_segmentation(pred_map)``
       — cell_segmentation/utils/post_proc_cellvit.py:33-153
   * ``calculate_instance_map(predictions, magnification)`` glue of CellViT — cellvit.py:332-383
+  * ``calculate_instances(pred_types, pred_insts)`` (ground-truth side of the evaluation callers) — post_proc_cellvit.py:252-330
 The numerical work (CC labelling, Sobel, marker watershed, per-instance records, contours) runs in
 libcellvit_amd.so on the GPU; this module only moves pointers and unpacks the record arrays.
 """
@@ -231,3 +232,32 @@ def calculate_instance_map(predictions: dict, num_nuclei_classes: int, magnifica
     hv = predictions["hv_map"]
     inst, recs, n_recs, contours, n_pts = postprocess_device(binm, typ, hv, num_nuclei_classes, object_size, k_size)
     return inst.float().cpu(), records_to_dicts(recs, n_recs, contours, n_pts)
+
+
+def calculate_instances(pred_types: torch.Tensor, pred_insts: torch.Tensor) -> List[dict]:
+    """post_proc_cellvit.py:252-330 ("best used for GT"): (one-hot / score type map [B, C, H, W], instance map [B, H, W])
+    -> per image {id: {bbox, centroid, contour, type_prob, type}} with the reference's conventions (np.unique()[1:] ids,
+    majority type with background replaced by the runner-up, instances whose contour has < 3 points dropped).
+    The per-instance statistics and the contour tracing are the P7/P8 kernels of the prediction path, run on the given
+    ids (`cv_pp_records`); only the record arrays come back to the host."""
+    if not pred_insts.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError("cellvit_amd post-processing runs on the MI355X only (no CPU fallback)")
+        pred_insts = pred_insts.cuda()
+    dev = pred_insts.device
+    B, H, W = pred_insts.shape
+    typ = argmax_channels(pred_types.to(dev)) if pred_types.shape[1] > 1 else torch.zeros((B, H, W), device=dev, dtype=torch.uint8)
+    nr_types = int(pred_types.shape[1])
+    e = _PPEngine.get(dev, B, H, W)
+    if int(pred_insts.max()) > H * W // 16:
+        raise CapacityError(f"instance ids above {H * W // 16} have no accumulator slot on a {H}x{W} tile: remap the labels first")
+    with torch.cuda.device(dev):
+        inst = pred_insts.to(torch.int32).contiguous().clone()
+        recs = torch.empty((B, e.max_inst, C.sizeof(_lib.cv_instance)), device=dev, dtype=torch.uint8)
+        n_recs = torch.zeros((B,), device=dev, dtype=torch.int32)
+        n_pts = torch.zeros((B,), device=dev, dtype=torch.int32)
+        contours = torch.empty((B, e.max_pts, 2), device=dev, dtype=torch.int32)
+        _lib.check(e.lib.cv_pp_records(e.h, inst.data_ptr(), typ.data_ptr(), B, min(nr_types, 8), recs.data_ptr(),
+                                       n_recs.data_ptr(), contours.data_ptr(), n_pts.data_ptr(),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return records_to_dicts(recs, n_recs, contours, n_pts)

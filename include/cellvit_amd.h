@@ -210,6 +210,12 @@ int cv_pp_run(cv_pp* pp, const uint8_t* bin_argmax, const uint8_t* type_argmax, 
 int cv_pp_run_params(cv_pp* pp, const uint8_t* bin_argmax, const uint8_t* type_argmax, const float* hv, int B,
                      int object_size, int ksize, int nr_types, int32_t* inst_map, cv_instance* recs,
                      int32_t* n_recs, int32_t* contours, int32_t* n_pts, void* stream);
+/* Records + contours of GIVEN instance maps: replaces calculate_instances (post_proc_cellvit.py:252-330, the
+ * ground-truth side of the evaluation callers, inference_cellvit_experiment_pannuke.py:744-746).  inst_map i32 [B,H,W]
+ * (device; ids <= 0 are background, negative ones are zeroed in place; ids above H*W/16 have no slot and are not
+ * reported), type_map u8 [B,H,W] (argmax of the one-hot type map; NULL with nr_types 0).  Outputs as cv_pp_run.       */
+int cv_pp_records(cv_pp* pp, int32_t* inst_map, const uint8_t* type_map, int B, int nr_types, cv_instance* recs,
+                  int32_t* n_recs, int32_t* contours, int32_t* n_pts, void* stream);
 /* Cell-token pooling of the inference CLI (cell_detection.py:396-409) on the device record arrays of cv_pp_run:
  * out[rec_offset[b] + i, :] = mean over tokens_nhwc[b, floor(rmin/p):ceil(rmax/p), floor(cmin/p):ceil(cmax/p), :] for
  * record i < n_recs[b] (indices cast to uint8 as the reference does).  rec_offset: int64 [B] device (exclusive prefix
