@@ -78,7 +78,10 @@ struct HostTensor {
 
 struct LinearW { void* W = nullptr; float* bias = nullptr; int N = 0, K = 0, ldw = 0;
                  void* W8 = nullptr; void* S8 = nullptr; };   // fp8 engine: e4m3 bytes [N, K] + E8M0 scale blocks (gemm.h)
-struct ConvW { void* W = nullptr; float* bias = nullptr; int Cout = 0, Ctot = 0, K = 0, ldw = 0; int relu = 1; int Cin_real = 0; };
+struct ConvW {
+    void* W = nullptr; float* bias = nullptr; int Cout = 0, Ctot = 0, K = 0, ldw = 0; int relu = 1; int Cin_real = 0;
+    void* Wkm = nullptr;     // fp16 engines, layers the implicit-GEMM convolution can take: the same filter in (64-channel chunk, tap, channel) K order
+};
 struct ConvTW { void* W = nullptr; float* bias4 = nullptr; int Cin = 0, Cout = 0, ldw = 0; };
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct HeadW { float* W = nullptr; float* b = nullptr; int n_out = 0; };
@@ -309,6 +312,15 @@ int pack_conv3(cv_handle* h, const std::string& conv_key, const std::string& bn_
     out->ldw = round_up(K, bk_of(h->cfg.compute_dtype));
     CVA_TRY(upload_matrix(h, wk.data(), Cout, K, out->ldw, &out->W));
     if (has_bias || g) CVA_TRY(upload_f32(h, bias.data(), Cout, &out->bias));
+    const int chunks = Cpad / 64;
+    if (!is_f32(h->cfg.compute_dtype) && Cout % 256 == 0 && Cpad % 64 == 0 && chunks >= 2 && (chunks & (chunks - 1)) == 0 && out->ldw == K) {
+        std::vector<float> wkm((size_t)Cout * K);
+        for (int co = 0; co < Cout; ++co)
+            for (int ch = 0; ch < chunks; ++ch)
+                for (int t = 0; t < 9; ++t)
+                    memcpy(&wkm[(size_t)co * K + ((size_t)ch * 9 + t) * 64], &wk[(size_t)co * K + (size_t)t * Cpad + ch * 64], 64 * sizeof(float));
+        CVA_TRY(upload_matrix(h, wkm.data(), Cout, K, out->ldw, &out->Wkm));
+    }
     return CV_OK;
 }
 
@@ -422,7 +434,14 @@ int run_conv3(const void* s1, int C1, const void* s2, int C2, const ConvW& w, vo
     p.out_mode = OUT_LINEAR; p.out_f32 = out_f32; p.out = out; p.ldc = w.Cout;
     ProfScope ps(KC_CONV3, 2.0 * p.M * (double)w.Cout * 9.0 * w.Cin_real, st);
     if (sizeof(T) == 2) {   // fp16 production path: halo-tiled direct convolution where the layer fits it
-        static const int conv_variant = cva_env_int("CVA_CONV", 2);
+        static const int conv_variant = cva_env_int("CVA_CONV", 3);   // 3: implicit GEMM on the 8-phase kernel where it fits, 2: halo kernel only, 1: generic
+        if (conv_variant == 3 && !head && !out_f32) {      // Cout % 256 == 0 layers: K = 9 * Cin as 64-channel tap steps of the 256 x 256 contraction
+            if (w.Wkm) { p.W = w.Wkm; p.conv_kmajor = 1; }
+            const int rc8 = launch_gemm8_conv3(p, st);
+            if (rc8 == 0) return CV_OK;
+            if (rc8 != -1) { cva_set_error("conv3x3 implicit-gemm launch failed (%d)", rc8); return CV_ERR_HIP; }
+            p.W = w.W; p.conv_kmajor = 0;
+        }
         if (conv_variant != 1) {
             p.zero = gemm_zero_page();
             static const int head_fuse = cva_env_int("CVA_HEADFUSE", 1);
@@ -1062,8 +1081,22 @@ extern "C" int cv_op_conv3x3(int dtype, const void* src1, int C1, const void* sr
     ConvW w; w.W = const_cast<void*>(Wk); w.bias = const_cast<float*>(bias); w.Cout = Cout; w.Ctot = C1 + C2; w.K = K; w.Cin_real = C1 + C2;
     w.ldw = K; w.relu = relu;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return dtype == CV_DTYPE_F16 ? run_conv3<half_t>(src1, C1, src2, C2, w, out, out_f32, B, H, W, st)
-                                 : run_conv3<float>(src1, C1, src2, C2, w, out, out_f32, B, H, W, st);
+    if (dtype != CV_DTYPE_F16) return run_conv3<float>(src1, C1, src2, C2, w, out, out_f32, B, H, W, st);
+    // as cv_finalize does for the model's layers: a second copy of the filter in the K order of the implicit-GEMM path, rebuilt
+    // on the caller's stream at every call into a grow-only scratch buffer (no allocation / synchronisation per call)
+    const int chunks = (C1 + C2) / 64;
+    if (Cout % 256 == 0 && (C1 + C2) % 64 == 0 && chunks >= 2 && (chunks & (chunks - 1)) == 0 && !out_f32) {
+        static void* scratch = nullptr; static size_t scratch_bytes = 0;
+        const size_t need = (size_t)Cout * K * 2;
+        if (need > scratch_bytes) {
+            if (scratch) { CVA_CHECK_HIP(hipDeviceSynchronize()); CVA_CHECK_HIP(hipFree(scratch)); scratch = nullptr; scratch_bytes = 0; }
+            CVA_CHECK_HIP(hipMalloc(&scratch, need));
+            scratch_bytes = need;
+        }
+        w.Wkm = scratch;
+        if (launch_conv_w_kmajor(Wk, w.Wkm, Cout, C1 + C2, st)) { cva_set_error("conv3x3: filter repack launch failed"); return CV_ERR_HIP; }
+    }
+    return run_conv3<half_t>(src1, C1, src2, C2, w, out, out_f32, B, H, W, st);
 }
 
 extern "C" int cv_op_convT2x2(int dtype, const void* src, const void* Wk, const float* bias4, void* out, int B, int H,

@@ -32,6 +32,9 @@ template <typename T> int launch_patchify(const float* x, const InputU8* u8, voi
 template <typename T> int launch_nchw3_to_nhwc8(const float* x, const InputU8* u8, void* out, int B, int H, int W, int CP, hipStream_t stream);
 
 // argmax over the channels of an fp32 NCHW map -> u8 [B, H*W] (first maximum, as torch.argmax; cellvit.py:366-374)
+// fp16 packed 3x3 filter [Cout][tap][Ctot] -> [Cout][Ctot/64][tap][64] (K order of the implicit-GEMM convolution); Ctot % 64 == 0
+int launch_conv_w_kmajor(const void* in, void* out, int Cout, int Ctot, hipStream_t stream);
+
 int launch_argmax_nchw(const float* x, uint8_t* out, int B, int C, long hw, hipStream_t stream);
 // u8 NHWC -> normalised fp32 NCHW [B,3,H*W] (the tensor the reference's DataLoader hands to model.forward)
 int launch_normalize_u8(const InputU8& u8, float* out, int B, long hw, hipStream_t stream);

@@ -490,6 +490,26 @@ int launch_argmax_nchw(const float* x, uint8_t* out, int B, int C, long hw, hipS
     return (int)hipGetLastError();
 }
 
+// Packed 3x3 filter [Cout][tap][Ctot] (fp16) -> [Cout][Ctot / 64][tap][64]: the K order of the implicit-GEMM convolution
+// (gemm8.hip, conv_kmajor), 16 bytes per thread.
+__global__ void conv_w_kmajor_kernel(const Piece* __restrict__ in, Piece* __restrict__ out, int Ctot, long total) {
+    const int pc = Ctot / 8;                                  // 16-byte pieces per tap
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long co = i / (9L * pc);
+        const int r = (int)(i - co * 9L * pc);                // position inside the output row
+        const int chunk = r / 72, q = r - chunk * 72, tap = q >> 3, c8 = q & 7;
+        out[i] = in[co * 9L * pc + (long)tap * pc + chunk * 8 + c8];
+    }
+}
+
+int launch_conv_w_kmajor(const void* in, void* out, int Cout, int Ctot, hipStream_t stream) {
+    if (Ctot % 64) return (int)hipErrorInvalidValue;
+    const long total = (long)Cout * 9 * (Ctot / 8);
+    hipLaunchKernelGGL(conv_w_kmajor_kernel, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const Piece*>(in),
+                       reinterpret_cast<Piece*>(out), Ctot, total);
+    return (int)hipGetLastError();
+}
+
 int launch_normalize_u8(const InputU8& u8, float* out, int B, long hw, hipStream_t stream) {
     const long total = (long)B * hw;
     hipLaunchKernelGGL(normalize_u8_kernel, dim3(grid_for(total)), dim3(256), 0, stream, u8.x, make_norm(&u8), out, hw, total);

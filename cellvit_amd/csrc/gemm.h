@@ -45,6 +45,8 @@ struct GemmParams {
     int a_rpi, a_extra, a_off;
     // A_CONV3 geometry: M = B*H*W output pixels, K = 9*(C1+C2)
     int H, Wd, C1, C2;
+    int conv_kmajor;                 // filter K order: 0 = (tap, channel) as packed by pack_conv3, 1 = (64-channel chunk, tap, channel)
+    int conv_wshift, conv_cshift;    // implicit 3x3 convolution on the 8-phase kernel: log2(W), log2((C1 + C2) / 64) (set by launch_gemm8_conv3)
     // ---- epilogue ----
     const float* bias;      // [N] or null
     int act;
@@ -86,6 +88,11 @@ int launch_gemm8_f8(const GemmParams& p, hipStream_t stream);
 
 // >= 256 B of zeros in device memory (DMA source for out-of-range pieces)
 void* gemm_zero_page();
+
+// gemm8.hip: implicit 3x3 convolution on the 8-phase kernel (Cout a multiple of 256, 64-channel K steps, power-of-two image
+// sides); GemmParams as for A_CONV3.  Returns -1 if the layer does not fit.
+bool gemm8_conv3_supported(const GemmParams& p);
+int launch_gemm8_conv3(const GemmParams& p, hipStream_t stream);
 
 // conv.hip: halo-tiled direct 3x3 convolution (fp16); GemmParams as for A_CONV3.  Returns -1 if the layer does not fit.
 int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream);

@@ -390,10 +390,11 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
     }
 }
 
-template <int OMODE, int TRANS, int ABL, int F8>
+template <int OMODE, int TRANS, int ABL, int F8, int CV3>
 __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     static_assert(!F8 || (TRANS == 1 && ABL == 0), "the fp8 variant exists for the direct (transposed) epilogues only");
+    static_assert(!CV3 || (OMODE == OUT_LINEAR && TRANS == 1 && !F8), "implicit 3x3 convolution: fp16, direct linear epilogue");
     constexpr int ESZ = F8 ? 1 : 2;                 // bytes per operand element; a tile row is 128 bytes either way
     constexpr int KTE = 128 / ESZ;                  // K elements per tile
 
@@ -416,6 +417,11 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     unsigned a_voff[4], w_voff[4];
     const unsigned char* Ab;
     const unsigned char* Wb;
+    // CV3 (implicit 3x3 convolution over NHWC pixels, see the header): tap-validity bits of the lane's four rows (9 bits each,
+    // two rows per register) and the tile's two buffer bases (source 1 / source 2 of a channel concat), both pointing at the
+    // top-left tap of the tile's first pixel so that every tap offset is non-negative.
+    unsigned cmask[2] = {0u, 0u};
+    unsigned long long cbase1 = 0, cbase2 = 0;
     // F8: this wave's 256-byte share of the tile's scale block pair.  Waves 0-3 fetch the A-side block (scales of the
     // operand that sits in the "A" LDS tile), waves 4-7 the W-side block; block (row tile, K tile) is 1 KiB.
     const unsigned char* Sb = nullptr;
@@ -432,6 +438,29 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         kstart = rev ? nk - 1 : 0; kstep = rev ? -1 : 1;
         // v columns of the fused qkv projection: exchange the operands (see epilogue8_vt); block-uniform
         swap = OMODE == OUT_QKV && TRANS == 1 && (n0 + p.n_off) >= 2 * p.D;
+        if (CV3) {
+            const int pim = m0 & (p.H * p.Wd - 1);          // first pixel of the tile inside its image (H*W a power of two)
+            cmask[0] = cmask[1] = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wave * 32 + i * 8 + lrow;
+                const int lp = lpc ^ ((row >> 1) & 7);
+                const int prow = (row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3);
+                const int pp = pim + row, y = pp >> p.conv_wshift, x = pp & (p.Wd - 1);
+                // tap t = ky*3 + kx reads pixel (y + ky - 1, x + kx - 1): bit t set = inside the image
+                const unsigned mk = (y > 0 ? 0x1FFu : 0x1F8u) & (y < p.H - 1 ? 0x1FFu : 0x03Fu) & (x > 0 ? 0x1FFu : 0x1B6u) &
+                                    (x < p.Wd - 1 ? 0x1FFu : 0x0DBu);
+                cmask[i >> 1] |= mk << ((i & 1) * 9);
+                a_voff[i] = (unsigned)(row * p.C1 * 2) + lp * 16;
+                w_voff[i] = (unsigned)((long)prow * p.ldw * 2) + lp * 16;
+            }
+            const long origin = ((long)m0 - p.Wd - 1) * p.C1 * 2;          // may lie before the tensor: only masked lanes would touch it
+            cbase1 = (unsigned long long)(reinterpret_cast<const unsigned char*>(p.A) + origin);
+            cbase2 = p.A2 ? (unsigned long long)(reinterpret_cast<const unsigned char*>(p.A2) + origin) : cbase1;
+            Ab = nullptr;
+            Wb = reinterpret_cast<const unsigned char*>(p.W) + (long)n0 * p.ldw * 2;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave * 32 + i * 8 + lrow;
@@ -475,7 +504,44 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 #define G8_DMA4(voff, base, ldsaddr)                                                                        \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), \
                  "s"(ldsaddr) : "memory")
+    // CV3: the A tile of K step k = (tap, 64-channel chunk) is 256 pixels x 64 channels of the tap-shifted image — one
+    // buffer-addressed LDS-DMA per 8 rows whose per-lane offset is the pixel's own row offset, the tap / chunk displacement is
+    // the instruction's scalar offset, and lanes whose tap falls outside the image carry an offset beyond the descriptor's
+    // range: the hardware then writes ZEROS into their LDS slots (measured, tools/probes/probe_buffer_lds_oob.hip) — the
+    // convolution's zero padding costs one select per piece and no memory traffic.
+#define G8_BDMA(voff, desc, soff, ldsaddr)                                                                   \
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(desc), \
+                 "s"(soff), "s"(ldsaddr) : "memory")
+    auto stage_a_conv = [&](int buf, int kt) {
+        const int kidx = kstart + kt * kstep;
+        int tap, ch;
+        if (p.conv_kmajor) {          // K order (64-channel chunk, tap): the nine taps of a chunk re-read the same L2 lines back to back
+            const int chunk = (kidx * 7282) >> 16;        // kidx / 9, exact for kidx < 4096
+            tap = __builtin_amdgcn_readfirstlane(kidx - chunk * 9);
+            ch = chunk * G8_BK;
+        } else {                      // K order (tap, channel): the packed filter layout of pack_conv3
+            tap = __builtin_amdgcn_readfirstlane(kidx >> p.conv_cshift);
+            ch = (kidx & ((1 << p.conv_cshift) - 1)) * G8_BK;
+        }
+        const bool second = ch >= p.C1;                               // block-uniform
+        const int ty = (tap * 11) >> 5, tx = tap - ty * 3;
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(((ty * p.Wd + tx) * p.C1 + (second ? ch - p.C1 : ch)) * 2));
+        const unsigned long long b = second ? cbase2 : cbase1;
+        i32x4_t d;
+        d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+        d[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));
+        d[2] = 0x40000000;                                            // num_records: valid offsets are tile-relative (< 2^30)
+        d[3] = 0x00020000;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G8_TILE + wave * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned ok = (cmask[i >> 1] >> ((i & 1) * 9 + tap)) & 1u;
+            const unsigned vo = ok ? a_voff[i] : 0x80000000u;
+            G8_BDMA(vo, d, soff, dst + i * 1024);
+        }
+    };
     auto stage_a = [&](int buf, int kt) {
+        if (CV3) { stage_a_conv(buf, kt); return; }
         if (F8) {      // the K tile's scale blocks first (oldest load of the stage: every counted wait that covers the tile covers them)
             const unsigned char* sbase = uniform_ptr(Sb + (long)(kstart + kt * kstep) * 1024);
             const unsigned sdst = __builtin_amdgcn_readfirstlane(lds0 + G8_SC + buf * 2048 + wave * 256);
@@ -730,11 +796,11 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     }
 }
 
-template <int OMODE, int TRANS, int ABL, int F8 = 0>
+template <int OMODE, int TRANS, int ABL, int F8 = 0, int CV3 = 0>
 int launch8(const GemmParams& p, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<OMODE, TRANS, ABL, F8>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<OMODE, TRANS, ABL, F8, CV3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr = true;
@@ -747,7 +813,7 @@ int launch8(const GemmParams& p, hipStream_t stream) {
     }
     const int tiles = (p.M / G8_BM) * (p.N / G8_BN);
     const int grid = (tiles < n_cu || (p.dbg & 32)) ? tiles : n_cu;   // persistent: one workgroup per CU walks tiles grid-stride
-    hipLaunchKernelGGL((gemm8_kernel<OMODE, TRANS, ABL, F8>), dim3(grid), dim3(G8_NT), G8_LDS, stream, p);
+    hipLaunchKernelGGL((gemm8_kernel<OMODE, TRANS, ABL, F8, CV3>), dim3(grid), dim3(G8_NT), G8_LDS, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -761,6 +827,30 @@ bool gemm8_supported(const GemmParams& p, int a_mode, size_t elem_size) {
     if ((256L + (p.a_rpi > 0 ? (256L / p.a_rpi + 1) * p.a_extra : 0)) * p.lda * 2 >= (1L << 31) || 256L * p.ldw * 2 >= (1L << 31)) return false;
     if (p.out_mode == OUT_QKV && (p.D % G8_BN || p.hd % 16 || p.N != 3 * p.D || p.n_off)) return false;
     return true;
+}
+
+// Implicit 3x3 convolution (stride 1, zero padding 1) on the 8-phase kernel: M = B*H*W NHWC pixels, N = Cout, K = 9 * (C1 + C2)
+// with k = tap * Ctot + c (the packed filter layout of pack_conv3).  Shapes it takes: Cout a multiple of 256, 64-channel K
+// steps that never straddle the two sources, power-of-two image sides (a 256-pixel tile never straddles two images).
+static int ilog2_exact(long v) { int s = 0; while ((1L << s) < v) ++s; return (1L << s) == v ? s : -1; }
+bool gemm8_conv3_supported(const GemmParams& p) {
+    const int Ctot = p.C1 + p.C2;
+    if (p.out_mode != OUT_LINEAR || p.out_f32 || p.res || p.head_W || !p.A || !p.W || !p.out) return false;
+    if (p.N % G8_BN || p.M % G8_BM || p.C1 % G8_BK || (p.C2 && (p.C2 != p.C1 || !p.A2))) return false;
+    if (ilog2_exact(Ctot / G8_BK) < 1 || ilog2_exact(p.Wd) < 0 || ilog2_exact((long)p.H * p.Wd) < 8) return false;
+    if (p.K != 9 * Ctot || p.ldw != p.K || p.ldc % 8 || ((size_t)p.A & 15) || ((size_t)p.A2 & 15) || ((size_t)p.W & 15)) return false;
+    if ((258L + 2L * p.Wd) * p.C1 * 2 >= (1L << 30) || 256L * p.ldw * 2 >= (1L << 31)) return false;
+    return true;
+}
+
+int launch_gemm8_conv3(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    if (!gemm8_conv3_supported(p)) return -1;
+    p.dbg = 0; p.epi_vec = 1; p.a_rpi = 0; p.o_rpi = 0;
+    { static const int km = cva_env_int("CVA_CONV_KMAJOR", -1); if (km >= 0) p.conv_kmajor = km; }   // ablation builds only (timing A/B)
+    p.conv_wshift = ilog2_exact(p.Wd);
+    p.conv_cshift = ilog2_exact((p.C1 + p.C2) / G8_BK);
+    return launch8<OUT_LINEAR, 1, 0, 0, 1>(p, stream);
 }
 
 bool gemm8_f8_supported(const GemmParams& p) {
