@@ -163,9 +163,9 @@ def main():
     from cellvit_amd.synth import synth_nuclei_maps
     from cellvit_amd.weights import make_state_dict, normalize_tile, synthetic_tile_u8
 
-    if _lib.load().cv_build_is_ablation():
-        print("bench.py: libcellvit_amd.so is an ABLATION build (-DCVA_ABLATION); rebuild with `python -m cellvit_amd.build`",
-              file=sys.stderr)
+    if _lib.load().cv_build_is_ablation() and not args.allow_debug_env:
+        print("bench.py: libcellvit_amd.so is an ABLATION build (-DCVA_ABLATION); rebuild with `python -m cellvit_amd.build` "
+              "(or pass --allow-debug-env for an experiment: the line then says so in config.experiment_env)", file=sys.stderr)
         sys.exit(3)
     cdt = "fp16" if args.dtype == "f16" else "fp8"
     if args.model == "samh":
@@ -297,7 +297,7 @@ def main():
             "config": {"workload": workload, "tile": T, "tiles_per_step_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"tile-sharded x{world}, no data-path collective",
                        "input": "raw uint8 HWC tiles resident in HBM; inference transform fused into the forward (cv_forward_u8)",
-                       "experiment_env": dbg,
+                       "experiment_env": dbg + (["ABLATION_BUILD"] if _lib.load().cv_build_is_ablation() else []),
                        "postproc": bool(do_pp), "postproc_stream_overlap": bool(overlap), "postproc_input": f"synthetic nuclei maps, {args.cells} cells/tile",
                        "instances_per_step": n_inst},
             "stage_ms_sequential": {"forward": fwd_ms, "postproc": pp_ms},

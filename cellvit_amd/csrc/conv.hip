@@ -271,6 +271,231 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Two-workgroups-per-CU variant for the layers with few channel chunks (the 64- and 128-channel layers at 512^2 / 1024^2: 2-8
+// chunks per tile).  With the kernel above ONE workgroup fills the CU (two 76.8-KB stages), so everything that is not MFMA
+// work — the address set-up, the first stage's DMA latency, the epilogue and the workgroup turn-over — is exposed: measured
+// 6.5 us + 1.6 us per chunk per workgroup against 2.2 us of MFMA work per chunk.  Here a workgroup is 4 waves with ONE stage
+// (76.8 KB), a wave owns 4 image rows = 128 pixels x 64 output channels (8 x 4 fragments, 128 accumulator VGPRs, 12 fragment
+// reads per 32 MFMAs instead of 8 per 16), and two workgroups share a CU: they run unsynchronised, so one's DMA waits,
+// prologue and epilogue overlap the other's MFMAs — ping-pong at workgroup granularity, no extra barriers.
+constexpr int NTH4 = 256, NWAVE4 = 4;
+constexpr int MAX_H4 = (HALO_INSTR + NWAVE4 - 1) / NWAVE4;   // 10
+constexpr int MAX_W4 = (W_INSTR + NWAVE4 - 1) / NWAVE4;      // 9
+
+__global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sH = smem;
+    unsigned char* sW = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = p.H, W = p.Wd;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ncb = (p.N + 63) / 64;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = t % ncb; t /= ncb;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; const int b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int n0 = cb * 64;
+    const int ctot = p.C1 + p.C2;
+
+    const half_t* __restrict__ S1 = reinterpret_cast<const half_t*>(p.A);
+    const half_t* __restrict__ S2 = reinterpret_cast<const half_t*>(p.A2);
+    const half_t* __restrict__ Wp = reinterpret_cast<const half_t*>(p.W);
+    const half_t* __restrict__ Zp = reinterpret_cast<const half_t*>(p.zero);
+
+    int h_pix[MAX_H4];   // pixel index * 4 + logical piece, or -1 (zero page)
+#pragma unroll
+    for (int i = 0; i < MAX_H4; ++i) {
+        const int k = wave + NWAVE4 * i;
+        const int hp = k * 16 + (lane >> 2);
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = k < HALO_INSTR && hp < HALO_PIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        h_pix[i] = ok ? ((((b * H + gy) * W + gx) << 2) | ((lane & 3) ^ swz(hp))) : -1;
+    }
+    int w_row[MAX_W4];
+#pragma unroll
+    for (int i = 0; i < MAX_W4; ++i) {
+        const int k = wave + NWAVE4 * i;
+        const int tap = k >> 2, n = (k & 3) * 16 + (lane >> 2);
+        const bool ok = k < W_INSTR && (n0 + n) < p.N;
+        w_row[i] = ok ? (n0 + n) * p.ldw + tap * ctot + ((lane & 3) ^ swz(n)) * 8 : -1;
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+
+    int a_hp[8];                                     // halo pixel of (fragment i, lane) for the centre tap: rows 4w .. 4w+3
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_hp[i] = (4 * wave + (i >> 1) + 1) * HW_ + ((i & 1) * 16 + li + 1);
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem;
+    unsigned b_ad[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int n = j * 16 + li; b_ad[j] = lds0 + HALO_BYTES + n * 64 + ((g ^ swz(n)) << 4); }
+
+    // One fragment set (48 VGPRs): the reads of a tap are issued in two halves, so the second half lands behind the first
+    // half's 16 MFMAs; the latency of the first half is covered by the OTHER workgroup's wave on the same SIMD.
+    half8_t Af[8], Bf[4];
+#define CV4_WAIT(n)                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                     \
+                 : "+v"(Af[0]), "+v"(Af[1]), "+v"(Af[2]), "+v"(Af[3]), "+v"(Af[4]), "+v"(Af[5]), "+v"(Af[6]),    \
+                   "+v"(Af[7]), "+v"(Bf[0]), "+v"(Bf[1]), "+v"(Bf[2]), "+v"(Bf[3])                               \
+                 :: "memory")
+#define CV4_RD_A(i, doff)                                                                                        \
+    do {                                                                                                         \
+        const int hp = a_hp[i] + (doff);                                                                         \
+        const unsigned ad = lds0 + hp * 64 + ((g ^ swz(hp)) << 4);                                               \
+        CV_DSR(Af[i], ad, 0);                                                                                    \
+    } while (0)
+#define CV4_STEP(TAP)                                                                                            \
+    do {                                                                                                         \
+        constexpr int doff = ((TAP) / 3 - 1) * HW_ + ((TAP) % 3 - 1);                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) CV_DSR(Bf[j], b_ad[j], (TAP) * 4096);                      \
+        CV4_RD_A(0, doff); CV4_RD_A(1, doff); CV4_RD_A(2, doff); CV4_RD_A(3, doff);                              \
+        CV4_RD_A(4, doff); CV4_RD_A(5, doff); CV4_RD_A(6, doff); CV4_RD_A(7, doff);                              \
+        CV4_WAIT(4);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[i], Bf[j], acc[i][j], 0, 0, 0);            \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        CV4_WAIT(0);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        _Pragma("unroll") for (int i = 4; i < 8; ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[i], Bf[j], acc[i][j], 0, 0, 0);            \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+
+    auto stage = [&](int ch) {
+        const int c0 = ch * 32;
+        const bool second = c0 >= p.C1;
+        const half_t* __restrict__ src = second ? S2 : S1;
+        const int cs = second ? p.C2 : p.C1;
+        const int cc = second ? c0 - p.C1 : c0;
+#pragma unroll
+        for (int i = 0; i < MAX_H4; ++i) {
+            const int k = wave + NWAVE4 * i;
+            if (k < HALO_INSTR) {                     // wave-uniform
+                const half_t* s = h_pix[i] >= 0 ? src + (long)(h_pix[i] >> 2) * cs + cc + (h_pix[i] & 3) * 8 : Zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                                 (__attribute__((address_space(3))) void*)(sH + k * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAX_W4; ++i) {
+            const int k = wave + NWAVE4 * i;
+            if (k < W_INSTR) {
+                const half_t* s = w_row[i] >= 0 ? Wp + w_row[i] + c0 : Zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                                 (__attribute__((address_space(3))) void*)(sW + k * 1024), 16, 0, 0);
+            }
+        }
+    };
+    const int nchunks = ctot / 32;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        stage(ch);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // (opaque per chunk: keeps the 72 tap addresses from being hoisted out of the loop into registers)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(a_hp[i]));
+        CV4_STEP(0); CV4_STEP(1); CV4_STEP(2);
+        CV4_STEP(3); CV4_STEP(4); CV4_STEP(5);
+        CV4_STEP(6); CV4_STEP(7); CV4_STEP(8);
+        __syncthreads();                                  // every wave has finished reading the stage
+    }
+
+    // ---- epilogue: as above, eight 16-pixel slabs per wave ----
+    float* st = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+    const bool fuse = p.head_W != nullptr;
+    float* hw = reinterpret_cast<float*>(smem + 36864);
+    if (fuse) {
+        for (int i = tid; i < p.head_nout * 65; i += NTH4)
+            hw[i] = i < p.head_nout * 64 ? p.head_W[i] : p.head_b[i - p.head_nout * 64];
+        __syncthreads();
+    }
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int n = n0 + j * 16 + li; bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] + bv[j];
+                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                st[(g * 4 + r) * 68 + j * 16 + li] = v;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int y = y0 + 4 * wave + (i >> 1);
+        const int xb = x0 + (i & 1) * 16;
+        if (fuse) {
+            const int rr = lane >> 2, part = lane & 3;
+            float ah[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) ah[n] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float v = st[rr * 68 + part * 16 + c];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) if (n < p.head_nout) ah[n] = fmaf(v, hw[n * 64 + part * 16 + c], ah[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) { ah[n] += __shfl_xor(ah[n], 1); ah[n] += __shfl_xor(ah[n], 2); }
+            const int x = xb + rr;
+            if (part == 0 && y < H && x < W) {
+                const long hwp = (long)H * W, pix = (long)y * W + x;
+                int best = 0; float bvv = 0.f;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    if (n < p.head_nout) {
+                        const float v = ah[n] + hw[p.head_nout * 64 + n];
+                        p.head_logits[((long)b * p.head_nout + n) * hwp + pix] = v;
+                        if (n == 0) bvv = v; else if (n < p.head_narg && v > bvv) { bvv = v; best = n; }
+                    }
+                }
+                if (p.head_argmax) p.head_argmax[(long)b * hwp + pix] = (uint8_t)best;
+            }
+        } else if (y < H) {
+            if (p.out_f32) {
+                float* out = reinterpret_cast<float*>(p.out);
+                for (int rr = lane >> 4; rr < 16; rr += 4) {
+                    const int x = xb + rr, n = n0 + (lane & 15) * 4;
+                    if (x < W && n < p.N) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 15) * 4);
+                        *reinterpret_cast<f32x4*>(out + (((long)b * H + y) * W + x) * p.ldc + n) = v;
+                    }
+                }
+            } else {
+                half_t* out = reinterpret_cast<half_t*>(p.out);
+                for (int rr = lane >> 3; rr < 16; rr += 8) {
+                    const int x = xb + rr, n = n0 + (lane & 7) * 8;
+                    if (x < W && n < p.N) {
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 7) * 8);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 7) * 8 + 4);
+                        half8_t o;
+                        o[0] = (half_t)lo[0]; o[1] = (half_t)lo[1]; o[2] = (half_t)lo[2]; o[3] = (half_t)lo[3];
+                        o[4] = (half_t)hi[0]; o[5] = (half_t)hi[1]; o[6] = (half_t)hi[2]; o[7] = (half_t)hi[3];
+                        *reinterpret_cast<half8_t*>(out + (((long)b * H + y) * W + x) * p.ldc + n) = o;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 // Returns -1 when the layer does not fit this kernel (caller uses the implicit-GEMM path).
@@ -288,6 +513,18 @@ int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
     }
     const int tiles = batch * ((p.H + TH - 1) / TH) * ((p.Wd + TW - 1) / TW);
     const dim3 grid(tiles * ((p.N + 63) / 64));
+    // few channel chunks per tile: the 4-wave single-stage kernel, two workgroups per CU (see conv3x3_halo4_kernel)
+    static const int halo4_max_chunks = cva_env_int("CVA_CONV_HALO4", 8);
+    if ((p.C1 + p.C2) / 32 <= halo4_max_chunks) {
+        static bool attr4 = false;
+        if (!attr4) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    CONV_LDS) != hipSuccess) return (int)hipGetLastError();
+            attr4 = true;
+        }
+        hipLaunchKernelGGL(conv3x3_halo4_kernel, grid, dim3(NTH4), CONV_LDS, stream, p);
+        return (int)hipGetLastError();
+    }
 #ifdef CVA_ABLATION
     static const int dbg = cva_env_int("CVA_CONV_DBG", 0);
     if (dbg) {

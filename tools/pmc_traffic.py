@@ -16,8 +16,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASSES = [  # (key in the json, substring of the kernel name); gemm8_kernel<OMODE, TRANS, ABL, F8>
-    ("mx8", "gemm8_kernel<0, 1, 0, 1>"), ("mx8", "gemm8_kernel<1, 1, 0, 1>"), ("mx8", "gemm8_kernel<3, 1, 0, 1>"),
+CLASSES = [  # (key in the json, substring of the kernel name); gemm8_kernel<OMODE, TRANS, ABL, F8, CV3>
+    ("mx8", "gemm8_kernel<0, 1, 0, 1, 0>"), ("mx8", "gemm8_kernel<1, 1, 0, 1, 0>"), ("mx8", "gemm8_kernel<3, 1, 0, 1, 0>"),
+    ("conv", "gemm8_kernel<0, 1, 0, 0, 1>"),
     ("linear", "gemm8_kernel<0"), ("qkv", "gemm8_kernel<1"), ("convT", "gemm8_kernel<2"), ("conv", "conv3x3_halo_kernel"),
     ("attn_global", "attn2_kernel"), ("attn_win", "attnwp_kernel"), ("layernorm_mx8", "layernorm_mx8_kernel"),
     ("layernorm", "layernorm_kernel"), ("layernorm_add", "layernorm_add_kernel"),
