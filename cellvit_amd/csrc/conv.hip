@@ -284,6 +284,7 @@ constexpr int NTH4 = 256, NWAVE4 = 4;
 constexpr int MAX_H4 = (HALO_INSTR + NWAVE4 - 1) / NWAVE4;   // 10
 constexpr int MAX_W4 = (W_INSTR + NWAVE4 - 1) / NWAVE4;      // 9
 
+template <int ABL = 0>      // ABL as in conv3x3_halo_kernel (ablation builds only)
 __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sH = smem;
@@ -307,25 +308,6 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
     const half_t* __restrict__ Wp = reinterpret_cast<const half_t*>(p.W);
     const half_t* __restrict__ Zp = reinterpret_cast<const half_t*>(p.zero);
 
-    int h_pix[MAX_H4];   // pixel index * 4 + logical piece, or -1 (zero page)
-#pragma unroll
-    for (int i = 0; i < MAX_H4; ++i) {
-        const int k = wave + NWAVE4 * i;
-        const int hp = k * 16 + (lane >> 2);
-        const int hy = hp / HW_, hx = hp - hy * HW_;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = k < HALO_INSTR && hp < HALO_PIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        h_pix[i] = ok ? ((((b * H + gy) * W + gx) << 2) | ((lane & 3) ^ swz(hp))) : -1;
-    }
-    int w_row[MAX_W4];
-#pragma unroll
-    for (int i = 0; i < MAX_W4; ++i) {
-        const int k = wave + NWAVE4 * i;
-        const int tap = k >> 2, n = (k & 3) * 16 + (lane >> 2);
-        const bool ok = k < W_INSTR && (n0 + n) < p.N;
-        w_row[i] = ok ? (n0 + n) * p.ldw + tap * ctot + ((lane & 3) ^ swz(n)) * 8 : -1;
-    }
-
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -340,40 +322,49 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int n = j * 16 + li; b_ad[j] = lds0 + HALO_BYTES + n * 64 + ((g ^ swz(n)) << 4); }
 
-    // One fragment set (48 VGPRs): the reads of a tap are issued in two halves, so the second half lands behind the first
-    // half's 16 MFMAs; the latency of the first half is covered by the OTHER workgroup's wave on the same SIMD.
-    half8_t Af[8], Bf[4];
-#define CV4_WAIT(n)                                                                                              \
+    // Fragment pipeline, half a tap ahead (64 fragment VGPRs): a tap is two halves of 16 MFMAs (fragments 0-3 / 4-7 of A against
+    // the four B fragments).  While the SECOND half of tap t multiplies (A_hi, B[t&1]), the reads of tap t+1's first half are in
+    // flight (A_lo is free again, B goes to the other B set); while the FIRST half of tap t+1 multiplies, the reads of its A_hi
+    // are in flight.  Every read has 16 MFMAs (256 matrix-pipe cycles) to land; only a chunk's first half-tap is exposed.
+    half8_t Af[8], Bf[2][4];
+#define CV4_WAIT(n, S)                                                                                           \
     asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                     \
                  : "+v"(Af[0]), "+v"(Af[1]), "+v"(Af[2]), "+v"(Af[3]), "+v"(Af[4]), "+v"(Af[5]), "+v"(Af[6]),    \
-                   "+v"(Af[7]), "+v"(Bf[0]), "+v"(Bf[1]), "+v"(Bf[2]), "+v"(Bf[3])                               \
+                   "+v"(Af[7]), "+v"(Bf[S][0]), "+v"(Bf[S][1]), "+v"(Bf[S][2]), "+v"(Bf[S][3])                   \
                  :: "memory")
-#define CV4_RD_A(i, doff)                                                                                        \
+#define CV4_RD_A(i, TAP)                                                                                         \
     do {                                                                                                         \
-        const int hp = a_hp[i] + (doff);                                                                         \
+        constexpr int doff_ = ((TAP) / 3 - 1) * HW_ + ((TAP) % 3 - 1);                                           \
+        const int hp = a_hp[i] + doff_;                                                                          \
         const unsigned ad = lds0 + hp * 64 + ((g ^ swz(hp)) << 4);                                               \
         CV_DSR(Af[i], ad, 0);                                                                                    \
     } while (0)
-#define CV4_STEP(TAP)                                                                                            \
+#define CV4_RD_LO(TAP)                                                                                           \
     do {                                                                                                         \
-        constexpr int doff = ((TAP) / 3 - 1) * HW_ + ((TAP) % 3 - 1);                                            \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) CV_DSR(Bf[j], b_ad[j], (TAP) * 4096);                      \
-        CV4_RD_A(0, doff); CV4_RD_A(1, doff); CV4_RD_A(2, doff); CV4_RD_A(3, doff);                              \
-        CV4_RD_A(4, doff); CV4_RD_A(5, doff); CV4_RD_A(6, doff); CV4_RD_A(7, doff);                              \
-        CV4_WAIT(4);                                                                                             \
+        CV4_RD_A(0, TAP); CV4_RD_A(1, TAP); CV4_RD_A(2, TAP); CV4_RD_A(3, TAP);                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) CV_DSR(Bf[(TAP) & 1][j], b_ad[j], (TAP) * 4096);           \
+    } while (0)
+#define CV4_RD_HI(TAP) do { CV4_RD_A(4, TAP); CV4_RD_A(5, TAP); CV4_RD_A(6, TAP); CV4_RD_A(7, TAP); } while (0)
+#define CV4_MMA(I0, S)                                                                                           \
+    do {                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+        if (!(ABL & 4))                                                                                          \
+        _Pragma("unroll") for (int i = (I0); i < (I0) + 4; ++i)                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[i], Bf[j], acc[i][j], 0, 0, 0);            \
-        __builtin_amdgcn_sched_barrier(0);                                                                       \
-        CV4_WAIT(0);                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                       \
-        _Pragma("unroll") for (int i = 4; i < 8; ++i)                                                            \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[i], Bf[j], acc[i][j], 0, 0, 0);            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[i], Bf[S][j], acc[i][j], 0, 0, 0);         \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
     } while (0)
+// in flight on entry: LO(TAP) [8 reads].  LAST: no prefetch of the next tap (the stage is about to be overwritten).
+#define CV4_STEP(TAP, LAST)                                                                                      \
+    do {                                                                                                         \
+        CV4_RD_HI(TAP);                                                                                          \
+        CV4_WAIT(4, (TAP) & 1);                       /* LO(TAP) landed, HI(TAP) in flight */                    \
+        CV4_MMA(0, (TAP) & 1);                                                                                   \
+        if (!(LAST)) { CV4_RD_LO((TAP) + 1); CV4_WAIT(8, (TAP) & 1); } else { CV4_WAIT(0, (TAP) & 1); }          \
+        CV4_MMA(4, (TAP) & 1);                                                                                   \
+    } while (0)
 
+    // DMA descriptors are recomputed per stage (a few dozen VALU instructions per chunk) instead of living in 19 VGPRs
     auto stage = [&](int ch) {
         const int c0 = ch * 32;
         const bool second = c0 >= p.C1;
@@ -383,8 +374,12 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
 #pragma unroll
         for (int i = 0; i < MAX_H4; ++i) {
             const int k = wave + NWAVE4 * i;
-            if (k < HALO_INSTR) {                     // wave-uniform
-                const half_t* s = h_pix[i] >= 0 ? src + (long)(h_pix[i] >> 2) * cs + cc + (h_pix[i] & 3) * 8 : Zp;
+            if (k < HALO_INSTR && !((ABL & 2) && ch > 0)) {                     // wave-uniform
+                const int hp = k * 16 + (lane >> 2);
+                const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                const bool ok = hp < HALO_PIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const half_t* s = ok ? src + (long)((b * H + gy) * W + gx) * cs + cc + ((lane & 3) ^ swz(hp)) * 8 : Zp;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
                                                  (__attribute__((address_space(3))) void*)(sH + k * 1024), 16, 0, 0);
             }
@@ -392,8 +387,9 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
 #pragma unroll
         for (int i = 0; i < MAX_W4; ++i) {
             const int k = wave + NWAVE4 * i;
-            if (k < W_INSTR) {
-                const half_t* s = w_row[i] >= 0 ? Wp + w_row[i] + c0 : Zp;
+            if (k < W_INSTR && !((ABL & 1) && ch > 0)) {
+                const int tap = k >> 2, n = (k & 3) * 16 + (lane >> 2);
+                const half_t* s = (n0 + n) < p.N ? Wp + (long)(n0 + n) * p.ldw + tap * ctot + ((lane & 3) ^ swz(n)) * 8 + c0 : Zp;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
                                                  (__attribute__((address_space(3))) void*)(sW + k * 1024), 16, 0, 0);
             }
@@ -407,9 +403,10 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
         // (opaque per chunk: keeps the 72 tap addresses from being hoisted out of the loop into registers)
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(a_hp[i]));
-        CV4_STEP(0); CV4_STEP(1); CV4_STEP(2);
-        CV4_STEP(3); CV4_STEP(4); CV4_STEP(5);
-        CV4_STEP(6); CV4_STEP(7); CV4_STEP(8);
+        CV4_RD_LO(0);
+        CV4_STEP(0, 0); CV4_STEP(1, 0); CV4_STEP(2, 0);
+        CV4_STEP(3, 0); CV4_STEP(4, 0); CV4_STEP(5, 0);
+        CV4_STEP(6, 0); CV4_STEP(7, 0); CV4_STEP(8, 1);
         __syncthreads();                                  // every wave has finished reading the stage
     }
 
@@ -518,11 +515,26 @@ int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
     if ((p.C1 + p.C2) / 32 <= halo4_max_chunks) {
         static bool attr4 = false;
         if (!attr4) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     CONV_LDS) != hipSuccess) return (int)hipGetLastError();
             attr4 = true;
         }
-        hipLaunchKernelGGL(conv3x3_halo4_kernel, grid, dim3(NTH4), CONV_LDS, stream, p);
+#ifdef CVA_ABLATION
+        static const int one_wg = cva_env_int("CVA_CONV_HALO4_ONE", 0);     // experiment: claim the whole LDS -> one workgroup per CU
+        if (one_wg) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(conv3x3_halo4_kernel<0>, grid, dim3(NTH4), 2 * CONV_LDS, stream, p);
+            return (int)hipGetLastError();
+        }
+        static const int dbg4 = cva_env_int("CVA_CONV_DBG", 0);
+        if (dbg4) {
+#define CVA_CONV4_ABL(A) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo4_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS); \
+                              hipLaunchKernelGGL(conv3x3_halo4_kernel<A>, grid, dim3(NTH4), CONV_LDS, stream, p); return (int)hipGetLastError(); } while (0)
+            switch (dbg4) { case 1: CVA_CONV4_ABL(1); case 2: CVA_CONV4_ABL(2); case 3: CVA_CONV4_ABL(3); case 4: CVA_CONV4_ABL(4); case 7: CVA_CONV4_ABL(7); default: break; }
+#undef CVA_CONV4_ABL
+        }
+#endif
+        hipLaunchKernelGGL(conv3x3_halo4_kernel<0>, grid, dim3(NTH4), CONV_LDS, stream, p);
         return (int)hipGetLastError();
     }
 #ifdef CVA_ABLATION
