@@ -318,8 +318,8 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
 // kernel with the operands exchanged (C^T = W_v . X^T: the "A" tile holds 256 W rows, the permuted "W" tile 256
 // token rows), so lane (g, li) holds, for column n = i*16 + li of the wave block, the 16 CONSECUTIVE tokens
 // g*16 .. g*16+15.  V^T is [S*heads, hd, Lp], contiguous along the token position: global attention gets
-// 16-byte stores, window-partitioned layers 4-byte stores of token pairs (a pair never straddles a window when
-// the window size and the grid width are even).
+// 16-byte stores, window-partitioned layers one 16-byte + 8- / 4-byte stores per run (grid width % 16 == 0) or, in general,
+// 4-byte stores of token pairs (a pair never straddles a window when the window size and the grid width are even).
 __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8][4], const float (&bvt)[16],
                                              const int nrow0, const int mcol0, const int lane) {
     const int g = lane >> 4, li = lane & 15;
@@ -327,10 +327,29 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
     half_t* vt = reinterpret_cast<half_t*>(p.vt_out);
     const int b0 = mb / p.ntok, t0 = mb - b0 * p.ntok;
     const bool fast = p.win == 0 && t0 + 15 < p.ntok && (t0 & 7) == 0;
+    // Window layers whose grid width is a multiple of 16 (1024-px tiles: 64): the lane's 16 tokens lie in ONE grid row and
+    // split into at most two runs that are contiguous in V^T — the rest of window wxA's row (lenA tokens from px = pxA) and
+    // the start of the next window's row.  With even window size all lengths are even: dwords 0-3 go out as one 16-byte
+    // store, dwords 4-7 as 8-byte stores where the pair stays inside a run and 4-byte stores where it straddles the window
+    // edge — 3.5 stores per lane and row on average instead of 8 (every store instruction of this epilogue touches 64
+    // different cache lines, so the count is the cost: the window layers' qkv launch was 24 % slower than the global ones').
+    bool wide = false;
+    long offA = 0, offB = 0; int nA = 8;
+    if (!fast && p.win >= 8 && (p.win & 1) == 0 && (p.gw & 15) == 0 && p.ntok == p.gh * p.gw && (t0 & 15) == 0) {
+        const int gy = t0 / p.gw, gx0 = t0 - gy * p.gw;
+        const int wy = gy / p.win, py = gy - wy * p.win;
+        const int wxA = gx0 / p.win, pxA = gx0 - wxA * p.win;
+        const int lenA = min(16, p.win - pxA);
+        nA = lenA >> 1;
+        const long sA = ((long)b0 * p.nwy + wy) * p.nwx + wxA;
+        offA = sA * p.heads * p.hd * p.Lp + py * p.win + pxA;
+        offB = (sA + 1) * p.heads * p.hd * p.Lp + py * p.win;
+        wide = __all(lenA >= 8 && (pxA & 1) == 0) != 0;          // wave-uniform: every lane's run A holds the 16-byte store
+    }
     // token -> offset inside one (s, h, d) row of V^T for the 16 tokens (8 pairs), walked incrementally (no divisions
     // per token; window index by float reciprocal, exact for coordinate * win < 2^21)
     long po0[8], po1[8]; bool pair_ok[8];
-    if (!fast) {
+    if (!fast && !wide) {
         const float inv_win = 1.0f / (float)(p.win > 0 ? p.win : 1);
         const bool fwin = p.win > 0 && p.gw <= 4096 && p.gh <= 4096 && p.win <= 256;
         int b = b0, t = t0, gy = 0, gx = 0;
@@ -372,6 +391,39 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
 #pragma unroll
                 for (int e = 0; e < 8; ++e) w[e] = (half_t)(acc[i][q * 2 + (e >> 2)][e & 3] + bv);
                 *reinterpret_cast<half8_t*>(dst + q * 8) = w;
+            }
+        } else if (wide) {
+            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+            typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+            half2_t dw[8];                                        // dword k = tokens 2k, 2k+1
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                dw[k][0] = (half_t)(acc[i][k >> 1][(k & 1) * 2] + bv);
+                dw[k][1] = (half_t)(acc[i][k >> 1][(k & 1) * 2 + 1] + bv);
+            }
+            half_t* rA = vt + offA + rowoff;
+            half_t* rB = vt + offB + rowoff - 2 * nA;             // run B holds dwords nA .. 7: dword k at rB + 2k
+            {
+                half8_t w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = dw[e >> 1][e & 1];
+                *reinterpret_cast<half8_t*>(rA) = w;
+            }
+            // dwords (4,5): both in A (nA >= 6), both in B (nA == 4), or split (nA == 5)
+            if (nA != 5) {
+                const half4_t w = {dw[4][0], dw[4][1], dw[5][0], dw[5][1]};
+                *reinterpret_cast<half4_t*>((nA >= 6 ? rA : rB) + 8) = w;
+            } else {
+                *reinterpret_cast<half2_t*>(rA + 8) = dw[4];
+                *reinterpret_cast<half2_t*>(rB + 10) = dw[5];
+            }
+            // dwords (6,7): both in A (nA == 8), both in B (nA <= 6), or split (nA == 7)
+            if (nA != 7) {
+                const half4_t w = {dw[6][0], dw[6][1], dw[7][0], dw[7][1]};
+                *reinterpret_cast<half4_t*>((nA == 8 ? rA : rB) + 12) = w;
+            } else {
+                *reinterpret_cast<half2_t*>(rA + 12) = dw[6];
+                *reinterpret_cast<half2_t*>(rB + 14) = dw[7];
             }
         } else {
 #pragma unroll
