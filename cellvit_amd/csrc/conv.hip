@@ -414,16 +414,69 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
     float* st = reinterpret_cast<float*>(smem) + wave * (16 * 68);
     const bool fuse = p.head_W != nullptr;
     float* hw = reinterpret_cast<float*>(smem + 36864);
+    // Fused 1x1 head (64 -> head_nout <= 8 channels, + argmax): two MFMAs per 16-pixel slab on the fp16 activations —
+    // C^T[out n][pixel] = W[n][:] . act[pixel][:], lane (g, li) then owns pixel li and outputs g*4 .. g*4+3 — instead of
+    // 16 * nout fp32 FMAs per lane and slab (the six-output type head cost 3.5 ms more per step than the two-output heads).
+    // Like the reference under autocast, the head multiplies fp16 activations by fp16 weights with fp32 accumulation.
+    half8_t wf[2]; f32x4 hb4 = (f32x4)(0.f);
+    wf[0] = (half8_t)(0); wf[1] = (half8_t)(0);
     if (fuse) {
         for (int i = tid; i < p.head_nout * 65; i += NTH4)
             hw[i] = i < p.head_nout * 64 ? p.head_W[i] : p.head_b[i - p.head_nout * 64];
         __syncthreads();
+        if (li < p.head_nout) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wf[ks][e] = (half_t)hw[li * 64 + ks * 32 + g * 8 + e];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (g * 4 + r < p.head_nout) hb4[r] = hw[p.head_nout * 64 + g * 4 + r];
     }
     float bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int n = n0 + j * 16 + li; bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f; }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        const int y = y0 + 4 * wave + (i >> 1);
+        const int xb = x0 + (i & 1) * 16;
+        if (fuse) {
+            half_t* sh = reinterpret_cast<half_t*>(st);          // [16 pixels][72]: 144-byte pitch, conflict-free 16-byte fragment reads
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bv[j];
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    sh[(g * 4 + r) * 72 + j * 16 + li] = (half_t)v;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const half8_t p0 = *reinterpret_cast<const half8_t*>(sh + li * 72 + g * 8);
+            const half8_t p1 = *reinterpret_cast<const half8_t*>(sh + li * 72 + 32 + g * 8);
+            f32x4 ha = hb4;
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], p0, ha, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], p1, ha, 0, 0, 0);
+            const int x = xb + li;
+            const bool valid = y < H && x < W;
+            const long hwp = (long)H * W, pix = (long)y * W + x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (valid && g * 4 + r < p.head_nout) p.head_logits[((long)b * p.head_nout + g * 4 + r) * hwp + pix] = ha[r];
+            // first maximum over outputs 0 .. head_narg-1 (strict >, ascending n): local over r, then lanes g = 0 | 1
+            float bvv = ha[0]; int best = g * 4;
+            if (g != 0 && !(g * 4 < p.head_narg)) bvv = -INFINITY;
+#pragma unroll
+            for (int r = 1; r < 4; ++r)
+                if (g * 4 + r < p.head_narg && ha[r] > bvv) { bvv = ha[r]; best = g * 4 + r; }
+            const float ov = __shfl_xor(bvv, 16);
+            const int oi = __shfl_xor(best, 16);
+            if (p.head_narg > 4 && ov > bvv) best = oi;
+            if (g == 0 && valid && p.head_argmax) p.head_argmax[(long)b * hwp + pix] = (uint8_t)best;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -434,36 +487,7 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int y = y0 + 4 * wave + (i >> 1);
-        const int xb = x0 + (i & 1) * 16;
-        if (fuse) {
-            const int rr = lane >> 2, part = lane & 3;
-            float ah[8];
-#pragma unroll
-            for (int n = 0; n < 8; ++n) ah[n] = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const float v = st[rr * 68 + part * 16 + c];
-#pragma unroll
-                for (int n = 0; n < 8; ++n) if (n < p.head_nout) ah[n] = fmaf(v, hw[n * 64 + part * 16 + c], ah[n]);
-            }
-#pragma unroll
-            for (int n = 0; n < 8; ++n) { ah[n] += __shfl_xor(ah[n], 1); ah[n] += __shfl_xor(ah[n], 2); }
-            const int x = xb + rr;
-            if (part == 0 && y < H && x < W) {
-                const long hwp = (long)H * W, pix = (long)y * W + x;
-                int best = 0; float bvv = 0.f;
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    if (n < p.head_nout) {
-                        const float v = ah[n] + hw[p.head_nout * 64 + n];
-                        p.head_logits[((long)b * p.head_nout + n) * hwp + pix] = v;
-                        if (n == 0) bvv = v; else if (n < p.head_narg && v > bvv) { bvv = v; best = n; }
-                    }
-                }
-                if (p.head_argmax) p.head_argmax[(long)b * hwp + pix] = (uint8_t)best;
-            }
-        } else if (y < H) {
+        if (y < H) {
             if (p.out_f32) {
                 float* out = reinterpret_cast<float*>(p.out);
                 for (int rr = lane >> 4; rr < 16; rr += 4) {
