@@ -477,6 +477,32 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
             __builtin_amdgcn_wave_barrier();
             continue;
         }
+        if (!p.out_f32) {                                        // fp16 output: the slab goes through LDS already rounded
+            half_t* sh = reinterpret_cast<half_t*>(st);          // [16 pixels][72]
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bv[j];
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    sh[(g * 4 + r) * 72 + j * 16 + li] = (half_t)v;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (y < H) {
+                half_t* out = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+                for (int rr = lane >> 3; rr < 16; rr += 8) {
+                    const int x = xb + rr, n = n0 + (lane & 7) * 8;
+                    if (x < W && n < p.N)
+                        *reinterpret_cast<half8_t*>(out + (((long)b * H + y) * W + x) * p.ldc + n) =
+                            *reinterpret_cast<const half8_t*>(sh + rr * 72 + (lane & 7) * 8);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -488,27 +514,12 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (y < H) {
-            if (p.out_f32) {
-                float* out = reinterpret_cast<float*>(p.out);
-                for (int rr = lane >> 4; rr < 16; rr += 4) {
-                    const int x = xb + rr, n = n0 + (lane & 15) * 4;
-                    if (x < W && n < p.N) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 15) * 4);
-                        *reinterpret_cast<f32x4*>(out + (((long)b * H + y) * W + x) * p.ldc + n) = v;
-                    }
-                }
-            } else {
-                half_t* out = reinterpret_cast<half_t*>(p.out);
-                for (int rr = lane >> 3; rr < 16; rr += 8) {
-                    const int x = xb + rr, n = n0 + (lane & 7) * 8;
-                    if (x < W && n < p.N) {
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 7) * 8);
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 7) * 8 + 4);
-                        half8_t o;
-                        o[0] = (half_t)lo[0]; o[1] = (half_t)lo[1]; o[2] = (half_t)lo[2]; o[3] = (half_t)lo[3];
-                        o[4] = (half_t)hi[0]; o[5] = (half_t)hi[1]; o[6] = (half_t)hi[2]; o[7] = (half_t)hi[3];
-                        *reinterpret_cast<half8_t*>(out + (((long)b * H + y) * W + x) * p.ldc + n) = o;
-                    }
+            float* out = reinterpret_cast<float*>(p.out);
+            for (int rr = lane >> 4; rr < 16; rr += 4) {
+                const int x = xb + rr, n = n0 + (lane & 15) * 4;
+                if (x < W && n < p.N) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 15) * 4);
+                    *reinterpret_cast<f32x4*>(out + (((long)b * H + y) * W + x) * p.ldc + n) = v;
                 }
             }
         }
