@@ -239,6 +239,10 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
                     half8_t w;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
+#ifdef CVA_ABLATION      // timing experiments (wrong results): 512 = store only the first 16 bytes of every 32, 1024 = only fragment rows i < 2
+                    if ((p.dbg & 512) && q == 1) continue;
+                    if ((p.dbg & 1024) && i >= 2) continue;
+#endif
                     *reinterpret_cast<half8_t*>(o + q * 8) = w;
                 }
             }
