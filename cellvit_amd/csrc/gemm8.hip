@@ -239,9 +239,16 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
                     half8_t w;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
-#ifdef CVA_ABLATION      // timing experiments (wrong results): 512 = store only the first 16 bytes of every 32, 1024 = only fragment rows i < 2
+#ifdef CVA_ABLATION      // timing experiments (wrong results): 512 = store only the first 16 bytes of every 32, 1024 = only fragment rows i < 2,
+                         // 4096 = full-line pattern: instruction q writes all eight 16-byte pieces of the rows with (li & 1) == q
                     if ((p.dbg & 512) && q == 1) continue;
                     if ((p.dbg & 1024) && i >= 2) continue;
+                    if (p.dbg & 4096) {
+                        const int lil = lane & 15;
+                        const long rsh = (long)((lil & 1) == q ? 0 : (q ? 1 : -1)) * p.ldc;     // partner row
+                        *reinterpret_cast<half8_t*>(o + rsh + ((lil & 1) ? 8 : 0)) = w;
+                        continue;
+                    }
 #endif
                     *reinterpret_cast<half8_t*>(o + q * 8) = w;
                 }
