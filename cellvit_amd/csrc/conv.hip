@@ -535,13 +535,11 @@ int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
     if (p.C1 % 32 != 0 || p.C2 % 32 != 0 || p.N % 8 != 0 || p.ldc % 8 != 0 || !p.zero) return -1;
     if (p.head_W) { if (p.N != 64 || p.head_nout < 1 || p.head_nout > 8 || !p.head_logits) return -1; }
     else if (((size_t)p.out & 15) != 0 || !p.out) return -1;
-    static int occ = -1;
-    if (occ < 0) {
-        occ = cva_env_int("CVA_CONV_OCC", 2);
+    static bool attr8 = false;
+    if (!attr8) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess) return (int)hipGetLastError();
+        attr8 = true;
     }
     const int tiles = batch * ((p.H + TH - 1) / TH) * ((p.Wd + TW - 1) / TW);
     const dim3 grid(tiles * ((p.N + 63) / 64));
@@ -582,8 +580,7 @@ int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
 #undef CVA_CONV_ABL
     }
 #endif
-    if (occ == 2) hipLaunchKernelGGL(conv3x3_halo_kernel<2>, grid, dim3(NTH), 2 * CONV_LDS, stream, p);
-    else hipLaunchKernelGGL(conv3x3_halo_kernel<4>, grid, dim3(NTH), 2 * CONV_LDS, stream, p);
+    hipLaunchKernelGGL(conv3x3_halo_kernel<2>, grid, dim3(NTH), 2 * CONV_LDS, stream, p);
     return (int)hipGetLastError();
 }
 
