@@ -38,6 +38,7 @@ class cv_outputs(C.Structure):
 SYMBOLS = {
     "cv_last_error": (C.c_char_p, []),
     "cv_build_is_ablation": (C.c_int, []),
+    "cv_build_flags": (C.c_char_p, []),
     "cv_create": (C.c_int, [C.POINTER(cv_config), C.POINTER(C.c_void_p)]),
     "cv_destroy": (C.c_int, [C.c_void_p]),
     "cv_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),

@@ -14,6 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libcellvit_amd.so")
+# The experiment flavour (-DCVA_ABLATION: CVA_* switches honoured, work-skipping instantiations present) has its own object
+# directory and its own library name: the product library can never be linked from, or mistaken for, ablation objects.
+OBJ_ABL = os.path.join(HERE, "csrc", "_obj_abl")
+LIB_ABL = os.path.join(HERE, "libcellvit_amd_abl.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
@@ -37,16 +41,20 @@ def _stale(out: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> str:
-    """ablation=True adds -DCVA_ABLATION (CVA_* experiment switches honoured; never used by bench.py / tests)."""
+    """ablation=True builds libcellvit_amd_abl.so with -DCVA_ABLATION (CVA_* experiment switches honoured; loaded only by
+    tools/ that ask for it, never by bench.py / tests / the product).  Extra compiler flags (CVA_BUILD_FLAGS) are accepted for
+    the ablation flavour only; the flags of either flavour are recorded in the library (cv_build_flags)."""
     hipcc = _hipcc()
+    OBJ, LIB = (OBJ_ABL, LIB_ABL) if ablation else (globals()["OBJ"], globals()["LIB"])
     os.makedirs(OBJ, exist_ok=True)
-    flags = FLAGS + (["-DCVA_ABLATION"] if ablation else []) + os.environ.get("CVA_BUILD_FLAGS", "").split()   # tuning experiments
-    stamp = os.path.join(OBJ, ".flavour")
-    flavour = ("ablation" if ablation else "production") + " " + os.environ.get("CVA_BUILD_FLAGS", "")
-    if not os.path.exists(stamp) or open(stamp).read().strip() != flavour.strip():
+    extra = os.environ.get("CVA_BUILD_FLAGS", "").split() if ablation else []
+    flags = FLAGS + (["-DCVA_ABLATION"] if ablation else []) + extra
+    flags = flags + ['-DCVA_BUILD_FLAGS_STR="' + " ".join(flags[1:]).replace('"', "'") + '"']
+    stamp = os.path.join(OBJ, ".flags")          # (untracked: _obj*/ is git-ignored)
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
         force = True
         with open(stamp, "w") as f:
-            f.write(flavour)
+            f.write(" ".join(flags))
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cellvit_amd.h"))
     jobs = []

@@ -26,6 +26,10 @@ void cva_set_error(const char* fmt, ...) {
 }
 extern "C" const char* cv_last_error(void) { return g_err; }
 extern "C" int cv_build_is_ablation(void) { return cva::CVA_ABLATION_BUILD; }
+#ifndef CVA_BUILD_FLAGS_STR
+#define CVA_BUILD_FLAGS_STR "unrecorded"
+#endif
+extern "C" const char* cv_build_flags(void) { return CVA_BUILD_FLAGS_STR; }
 
 using namespace cva;
 
@@ -594,13 +598,16 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
     }
     if (zi != 4) { cva_set_error("extract_layers must name 4 distinct blocks"); return CV_ERR_INVALID; }
 
-    // ---- tissue-type head (F6) ----
-    if (out->tissue_types && c.num_tissue_classes > 0) {
+    // ---- tissue-type head (F6).  num_tissue_classes == 0: the reference's head is nn.Identity and `tissue_types` is the
+    // pooled embedding itself (vits_histo.py:359-362 -> norm(x)[:, 0], [B, D]; cellvit.py:568-572 -> mean of the neck, [B, C]) ----
+    if (out->tissue_types) {
+        const bool ident = c.num_tissue_classes <= 0;
         if (c.arch == CV_ARCH_VIT) {
-            CVA_LAUNCH(launch_layernorm<T>(h->resid, (long)ntok * D, h->final_norm.g, h->final_norm.b, h->small_T, 0, B,
-                                           D, LN_EPS, st));
-            CVA_TRY(run_linear<T>(h->small_T, D, h->vit_head, nullptr, 0, 0, out->tissue_types, c.num_tissue_classes,
-                                  1, B, ACT_NONE, st));
+            CVA_LAUNCH(launch_layernorm<T>(h->resid, (long)ntok * D, h->final_norm.g, h->final_norm.b,
+                                           ident ? out->tissue_types : h->small_T, ident ? 1 : 0, B, D, LN_EPS, st));
+            if (!ident)
+                CVA_TRY(run_linear<T>(h->small_T, D, h->vit_head, nullptr, 0, 0, out->tissue_types, c.num_tissue_classes,
+                                      1, B, ACT_NONE, st));
         } else {
             const int C = c.neck_chans;
             CVA_LAUNCH(launch_cast_tokens<T>(h->resid, h->xn, B, ntok, 0, D, st));
@@ -608,10 +615,12 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
             CVA_LAUNCH(launch_layernorm<T>(h->neck_f32a, C, h->neck1.g, h->neck1.b, h->attn_out, 0, M, C, LN_EPS, st));
             CVA_TRY(run_conv3<T>(h->attn_out, C, nullptr, 0, h->neck2, h->neck_f32a, 1, B, g.gh, g.gw, st));
             CVA_LAUNCH(launch_layernorm<T>(h->neck_f32a, C, h->neck3.g, h->neck3.b, h->neck_f32b, 1, M, C, LN_EPS, st));
-            CVA_LAUNCH(launch_mean_rows(h->neck_f32b, h->small_f32, B, P, C, st));
-            CVA_LAUNCH(launch_cast<T>(h->small_f32, h->small_T, (long)B * C, st));
-            CVA_TRY(run_linear<T>(h->small_T, C, h->cls_head, nullptr, 0, 0, out->tissue_types, c.num_tissue_classes,
-                                  1, B, ACT_NONE, st));
+            CVA_LAUNCH(launch_mean_rows(h->neck_f32b, ident ? reinterpret_cast<float*>(out->tissue_types) : h->small_f32, B, P, C, st));
+            if (!ident) {
+                CVA_LAUNCH(launch_cast<T>(h->small_f32, h->small_T, (long)B * C, st));
+                CVA_TRY(run_linear<T>(h->small_T, C, h->cls_head, nullptr, 0, 0, out->tissue_types, c.num_tissue_classes,
+                                      1, B, ACT_NONE, st));
+            }
         }
     }
 

@@ -1,0 +1,352 @@
+// Pieces shared by the 256 x 256 x 64 fp16 contraction kernels (gemm8.hip: 8 waves, 8-phase schedule; gemm4.hip: 4 waves,
+// one per SIMD, 128 x 128 accumulators per wave): LDS map, DMA helpers, and the direct epilogues on TRANSPOSED accumulator
+// fragments of a 128 x 64 wave block.
+#pragma once
+#include "gemm.h"
+#include "gemm_epilogue.h"
+
+namespace cva {
+namespace g8 {
+
+using namespace epi;
+
+constexpr int G8_BM = 256, G8_BN = 256, G8_BK = 64, G8_NT = 512;
+constexpr int G8_TILE = 256 * 128;          // bytes of one A or W tile (256 rows x 128 B)
+constexpr int G8_WOFF = 2 * G8_TILE;        // LDS layout: [E.A][O.A][E.W][O.W] -> buffer select = +32 KiB immediate offset
+constexpr int G8_BIAS = 4 * G8_TILE;       // two 1-KiB bias slots (256 floats each, alternating per output tile)
+constexpr int G8_LUT = 4 * G8_TILE + 2048;  // GELU: Phi(x) at x = -8 + i/128, i = 0 .. 2048 (fp32), filled once per workgroup
+constexpr int G8_LUTN = 2048;
+constexpr int G8_SC = G8_LUT + (G8_LUTN + 1) * 4 + 12;      // F8: scale images, [E | O] x [A-side 1 KiB | W-side 1 KiB]
+constexpr int G8_LDS = G8_SC + 4096;
+
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+// Pin a wave-uniform pointer into SGPRs (opaque to the optimiser): the DMA then uses the
+// `global_load_lds v_off, s[base:base+1]` form instead of per-lane 64-bit induction pointers.
+__device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char* q) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+}
+
+
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the
+// fp16 rounding of the result).  Written in erfc form so that large negative x does not cancel:
+//   q = 0.5 x P(t) exp(-x^2/2), t = 1 / (1 + 0.3275911 |x| / sqrt 2);   gelu = x >= 0 ? x - q : q.
+__device__ __forceinline__ float gelu_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678f, 1.0f));
+    float pl = fmaf(t, 1.061405429f, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    pl *= t;
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504089f));
+    const float q = 0.5f * x * pl * e;
+    return x >= 0.f ? x - q : q;
+}
+
+// GELU on the 8-phase path: x * Phi(x) with Phi linearly interpolated in the LDS table (h = 1/128: |dPhi| <= h^2/8 |x phi(x)|
+// < 1.9e-6 absolute and < 2e-4 relative everywhere, i.e. below half an fp16 ulp of the result); 8 full-rate VALU + one
+// ds_read2_b32 per element instead of 12 + rcp + exp.  x <= -8 -> x * 6e-16, x >= 8 -> x.
+__device__ __forceinline__ float gelu_lut(float x, const float* lut) {
+    float u = fmaf(x, 128.f, 1024.f);
+    u = __builtin_amdgcn_fmed3f(u, 0.f, 2047.999f);
+    const float fr = __builtin_amdgcn_fractf(u);
+    const int i = (int)u;
+    const float t0 = lut[i], t1 = lut[i + 1];
+    return x * fmaf(fr, t1 - t0, t0);
+}
+
+// Direct epilogue for the TRANSPOSED accumulator orientation (C^T fragments: lane (g, li) holds, for row
+// m = i*16 + li of the wave block, the 16 CONSECUTIVE columns g*16 .. g*16+15 — the W rows are permuted at DMA
+// time to make them consecutive).  No LDS: bias / activation / residual on registers, 16-byte stores.
+template <int OMODE>
+__device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&acc)[8][4], const float (&bv)[16],
+                                                 const int mrow0, const int ncol0, const int lane, const float* lut) {
+    const int g = lane >> 4, li = lane & 15;
+    const int n = ncol0 + g * 16;
+    half_t* qk = nullptr;
+    long col_term = 0;
+    if (OMODE == OUT_QKV) {
+        const int nn = n + p.n_off;
+        const int which = nn / p.D;
+        const int c = nn - which * p.D;
+        const int h = c / p.hd, d = c - h * p.hd;           // 16 consecutive d inside one head (hd % 16 == 0)
+        qk = reinterpret_cast<half_t*>(which == 0 ? p.q_out : p.k_out);
+        col_term = (long)h * p.L * p.hd + d;
+    }
+    // OUT_QKV: token m -> (image b, token t, grid row gy, grid col gx), advanced by 16 tokens per fragment row without
+    // integer divisions; the window index of a grid coordinate is a float reciprocal (exact: coordinate * win < 2^21)
+    int tb = 0, tt = 0, tgy = 0, tgx = 0;
+    const float inv_win = 1.0f / (float)(p.win > 0 ? p.win : 1);
+    const bool fwin = p.win > 0 && p.gw <= 4096 && p.gh <= 4096 && p.win <= 256;
+    if (OMODE == OUT_QKV) {
+        const int m_first = mrow0 + li;
+        tb = m_first / p.ntok; tt = m_first - tb * p.ntok;
+        if (p.win > 0) { tgy = tt / p.gw; tgx = tt - tgy * p.gw; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = mrow0 + i * 16 + li;
+        float v[16];
+        if (p.act == ACT_GELU) {                        // (uniform branches: one activation's code per launch, no selects)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[j * 4 + r] = gelu_lut(acc[i][j][r] + bv[j * 4 + r], lut);
+        } else if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaxf(acc[i][j][r] + bv[j * 4 + r], 0.f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] + bv[j * 4 + r];
+        }
+        if (OMODE == OUT_LINEAR) {
+            long orow = m;
+            if (p.o_rpi > 0) orow = (long)m + (long)(m / p.o_rpi) * p.o_extra + p.o_off;
+            if (p.res) {
+                const long rrow = p.res_mod > 0 ? (long)(m % p.res_mod) : orow;
+                const float* rp = p.res + rrow * p.ldres + n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(rp + q * 4);
+                    v[q * 4 + 0] += r4[0]; v[q * 4 + 1] += r4[1]; v[q * 4 + 2] += r4[2]; v[q * 4 + 3] += r4[3];
+                }
+            }
+            if (p.out_f32) {
+                float* o = reinterpret_cast<float*>(p.out) + orow * (long)p.ldc + n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = {v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+                    *reinterpret_cast<f32x4*>(o + q * 4) = w;
+                }
+            } else {
+                half_t* o = reinterpret_cast<half_t*>(p.out) + orow * (long)p.ldc + n;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    half8_t w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
+#ifdef CVA_ABLATION      // timing experiments (wrong results): 512 = store only the first 16 bytes of every 32, 1024 = only fragment rows i < 2,
+                         // 4096 = full-line pattern: instruction q writes all eight 16-byte pieces of the rows with (li & 1) == q
+                    if ((p.dbg & 512) && q == 1) continue;
+                    if ((p.dbg & 1024) && i >= 2) continue;
+                    if (p.dbg & 4096) {
+                        const int lil = lane & 15;
+                        const long rsh = (long)((lil & 1) == q ? 0 : (q ? 1 : -1)) * p.ldc;     // partner row
+                        *reinterpret_cast<half8_t*>(o + rsh + ((lil & 1) ? 8 : 0)) = w;
+                        continue;
+                    }
+#endif
+                    *reinterpret_cast<half8_t*>(o + q * 8) = w;
+                }
+            }
+        } else if (OMODE == OUT_MX8) {
+            // MX-fp8 output (the hidden activation of the MLP, consumed as the A operand of fc2): a 32-column scale block is
+            // this lane's 16 values + those of lane ^ 16 (g ^ 1).  OCP MX: shared exponent = floor(log2(amax)) - 8 (e4m3 emax),
+            // elements = v * 2^-shared, saturated to +-448, round to nearest even (v_cvt_pk_fp8_f32).
+            float amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(v[e]));
+            amax = fmaxf(amax, __shfl_xor(amax, 16));
+            const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);          // biased exponent of amax (0 for zero / denormal)
+            int sbyte = ex - 8; sbyte = sbyte < 0 ? 0 : sbyte;                  // E8M0 byte = shared exponent + 127
+            const float inv = __uint_as_float((unsigned)(254 - sbyte) << 23);   // 2^-(sbyte - 127)
+            i32x4_t w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int pk = 0;
+                const float x0 = __builtin_amdgcn_fmed3f(v[q * 4 + 0] * inv, -448.f, 448.f), x1 = __builtin_amdgcn_fmed3f(v[q * 4 + 1] * inv, -448.f, 448.f);
+                const float x2 = __builtin_amdgcn_fmed3f(v[q * 4 + 2] * inv, -448.f, 448.f), x3 = __builtin_amdgcn_fmed3f(v[q * 4 + 3] * inv, -448.f, 448.f);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, pk, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, pk, true);
+                w[q] = pk;
+            }
+            unsigned char* o8 = reinterpret_cast<unsigned char*>(p.out) + (long)m * p.ldc + n;
+            *reinterpret_cast<i32x4_t*>(o8) = w;
+            if (!(g & 1))
+                reinterpret_cast<unsigned char*>(p.out_scale)[mx8_scale_index(m, n, p.N, false)] = (unsigned char)sbyte;
+        } else if (OMODE == OUT_CONVT) {
+            // ConvTranspose2d k2 s2: row m = input pixel (b, y, x), column n = (dy*2 + dx) * Cout + co; the lane's 16 columns
+            // are 16 consecutive co of one (dy, dx) (Cout % 16 == 0): one 32-byte run of output pixel (2y + dy, 2x + dx).
+            // The up-sampled activation is streamed out once and read much later: nontemporal stores.
+            const int cout = p.N >> 2;
+            const int dd = n / cout, co = n - dd * cout;
+            const int hw = p.H * p.Wd;
+            const int b = m / hw, r2 = m - b * hw;
+            const int y = r2 / p.Wd, x = r2 - y * p.Wd;
+            half_t* o = reinterpret_cast<half_t*>(p.out) +
+                        (((long)b * 2 * p.H + 2 * y + (dd >> 1)) * (2 * p.Wd) + 2 * x + (dd & 1)) * cout + co;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                half8_t w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
+                __builtin_nontemporal_store(w, reinterpret_cast<half8_t*>(o + q * 8));
+            }
+        } else {   // OUT_QKV, q or k columns
+            int s_ = tb, pos = tt;
+            if (p.win > 0) {
+                const int wy = fwin ? (int)(((float)tgy + 0.5f) * inv_win) : tgy / p.win;
+                const int wx = fwin ? (int)(((float)tgx + 0.5f) * inv_win) : tgx / p.win;
+                s_ = (tb * p.nwy + wy) * p.nwx + wx;
+                pos = (tgy - wy * p.win) * p.win + (tgx - wx * p.win);
+            }
+            // next fragment row: 16 tokens further
+            tt += 16; tgx += 16;
+            if (tt >= p.ntok) {
+                tt -= p.ntok; ++tb;
+                if (p.win > 0) { tgy = tt / p.gw; tgx = tt - tgy * p.gw; }
+            } else if (p.win > 0) {
+                while (tgx >= p.gw) { tgx -= p.gw; ++tgy; }
+            }
+            half_t* o = qk + ((long)s_ * p.heads * p.L + pos) * p.hd + col_term;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                half8_t w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
+                *reinterpret_cast<half8_t*>(o + q * 8) = w;
+            }
+        }
+    }
+}
+
+
+// Direct V^T epilogue for the v columns of the fused qkv projection.  Those tiles run the SAME transposed
+// kernel with the operands exchanged (C^T = W_v . X^T: the "A" tile holds 256 W rows, the permuted "W" tile 256
+// token rows), so lane (g, li) holds, for column n = i*16 + li of the wave block, the 16 CONSECUTIVE tokens
+// g*16 .. g*16+15.  V^T is [S*heads, hd, Lp], contiguous along the token position: global attention gets
+// 16-byte stores, window-partitioned layers one 16-byte + 8- / 4-byte stores per run (grid width % 16 == 0) or, in general,
+// 4-byte stores of token pairs (a pair never straddles a window when the window size and the grid width are even).
+__device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8][4], const float (&bvt)[16],
+                                             const int nrow0, const int mcol0, const int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    const int mb = mcol0 + g * 16;                               // first of this lane's 16 tokens
+    half_t* vt = reinterpret_cast<half_t*>(p.vt_out);
+    const int b0 = mb / p.ntok, t0 = mb - b0 * p.ntok;
+    const bool fast = p.win == 0 && t0 + 15 < p.ntok && (t0 & 7) == 0;
+    // Window layers whose grid width is a multiple of 16 (1024-px tiles: 64): the lane's 16 tokens lie in ONE grid row and
+    // split into at most two runs that are contiguous in V^T — the rest of window wxA's row (lenA tokens from px = pxA) and
+    // the start of the next window's row.  With even window size all lengths are even: dwords 0-3 go out as one 16-byte
+    // store, dwords 4-7 as 8-byte stores where the pair stays inside a run and 4-byte stores where it straddles the window
+    // edge — 3.5 stores per lane and row on average instead of 8 (every store instruction of this epilogue touches 64
+    // different cache lines, so the count is the cost: the window layers' qkv launch was 24 % slower than the global ones').
+    bool wide = false;
+    long offA = 0, offB = 0; int nA = 8;
+    if (!fast && p.win >= 8 && (p.win & 1) == 0 && (p.gw & 15) == 0 && p.ntok == p.gh * p.gw && (t0 & 15) == 0) {
+        const int gy = t0 / p.gw, gx0 = t0 - gy * p.gw;
+        const int wy = gy / p.win, py = gy - wy * p.win;
+        const int wxA = gx0 / p.win, pxA = gx0 - wxA * p.win;
+        const int lenA = min(16, p.win - pxA);
+        nA = lenA >> 1;
+        const long sA = ((long)b0 * p.nwy + wy) * p.nwx + wxA;
+        offA = sA * p.heads * p.hd * p.Lp + py * p.win + pxA;
+        offB = (sA + 1) * p.heads * p.hd * p.Lp + py * p.win;
+        wide = __all(lenA >= 8 && (pxA & 1) == 0) != 0;          // wave-uniform: every lane's run A holds the 16-byte store
+    }
+    // token -> offset inside one (s, h, d) row of V^T for the 16 tokens (8 pairs), walked incrementally (no divisions
+    // per token; window index by float reciprocal, exact for coordinate * win < 2^21)
+    long po0[8], po1[8]; bool pair_ok[8];
+    if (!fast && !wide) {
+        const float inv_win = 1.0f / (float)(p.win > 0 ? p.win : 1);
+        const bool fwin = p.win > 0 && p.gw <= 4096 && p.gh <= 4096 && p.win <= 256;
+        int b = b0, t = t0, gy = 0, gx = 0;
+        if (p.win > 0) { gy = t / p.gw; gx = t - gy * p.gw; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            long o[2];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                int s_ = b, pos = t;
+                if (p.win > 0) {
+                    const int wy = fwin ? (int)(((float)gy + 0.5f) * inv_win) : gy / p.win;
+                    const int wx = fwin ? (int)(((float)gx + 0.5f) * inv_win) : gx / p.win;
+                    s_ = (b * p.nwy + wy) * p.nwx + wx;
+                    pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
+                }
+                o[w] = (long)s_ * p.heads * p.hd * p.Lp + pos;
+                ++t; ++gx;
+                if (t >= p.ntok) { t = 0; ++b; gy = 0; gx = 0; }
+                else if (p.win > 0 && gx >= p.gw) { gx = 0; ++gy; }
+            }
+            po0[u] = o[0]; po1[u] = o[1];
+            pair_ok[u] = (o[1] == o[0] + 1) && ((o[0] & 1) == 0);
+        }
+    }
+    const int c0 = nrow0 + li + p.n_off - 2 * p.D;              // v column of fragment row 0; +16 per fragment row
+    int h = c0 / p.hd, d = c0 - h * p.hd;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float bv = bvt[i];
+        const long rowoff = ((long)h * p.hd + d) * p.Lp;
+        d += 16;
+        while (d >= p.hd) { d -= p.hd; ++h; }
+        if (fast) {
+            half_t* dst = vt + (long)b0 * p.heads * p.hd * p.Lp + rowoff + t0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                half8_t w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = (half_t)(acc[i][q * 2 + (e >> 2)][e & 3] + bv);
+                *reinterpret_cast<half8_t*>(dst + q * 8) = w;
+            }
+        } else if (wide) {
+            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+            typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+            half2_t dw[8];                                        // dword k = tokens 2k, 2k+1
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                dw[k][0] = (half_t)(acc[i][k >> 1][(k & 1) * 2] + bv);
+                dw[k][1] = (half_t)(acc[i][k >> 1][(k & 1) * 2 + 1] + bv);
+            }
+            half_t* rA = vt + offA + rowoff;
+            half_t* rB = vt + offB + rowoff - 2 * nA;             // run B holds dwords nA .. 7: dword k at rB + 2k
+            {
+                half8_t w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = dw[e >> 1][e & 1];
+                *reinterpret_cast<half8_t*>(rA) = w;
+            }
+            // dwords (4,5): both in A (nA >= 6), both in B (nA == 4), or split (nA == 5)
+            if (nA != 5) {
+                const half4_t w = {dw[4][0], dw[4][1], dw[5][0], dw[5][1]};
+                *reinterpret_cast<half4_t*>((nA >= 6 ? rA : rB) + 8) = w;
+            } else {
+                *reinterpret_cast<half2_t*>(rA + 8) = dw[4];
+                *reinterpret_cast<half2_t*>(rB + 10) = dw[5];
+            }
+            // dwords (6,7): both in A (nA == 8), both in B (nA <= 6), or split (nA == 7)
+            if (nA != 7) {
+                const half4_t w = {dw[6][0], dw[6][1], dw[7][0], dw[7][1]};
+                *reinterpret_cast<half4_t*>((nA == 8 ? rA : rB) + 12) = w;
+            } else {
+                *reinterpret_cast<half2_t*>(rA + 12) = dw[6];
+                *reinterpret_cast<half2_t*>(rB + 14) = dw[7];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const half_t v0 = (half_t)(acc[i][u >> 1][(u & 1) * 2] + bv), v1 = (half_t)(acc[i][u >> 1][(u & 1) * 2 + 1] + bv);
+                if (pair_ok[u]) {
+                    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+                    const half2_t w = {v0, v1};
+                    *reinterpret_cast<half2_t*>(vt + po0[u] + rowoff) = w;
+                } else {
+                    vt[po0[u] + rowoff] = v0;
+                    vt[po1[u] + rowoff] = v1;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace g8
+}  // namespace cva

@@ -282,6 +282,7 @@ class CellSegmentationInference:
         norm = self.run_conf.get("transformations", {}).get("normalize", {})
         self.mean = tuple(float(v) for v in norm.get("mean", (0.5, 0.5, 0.5)))
         self.std = tuple(float(v) for v in norm.get("std", (0.5, 0.5, 0.5)))
+        self.pool_cap = 2048       # fixed token-pooling slots per tile; tiles with more records take the exact-size pass
 
     def _normalize(self, tiles_u8: torch.Tensor) -> torch.Tensor:
         """T.ToTensor + T.Normalize (:214-227) as a stand-alone device op: [B,H,W,3] u8 -> [B,3,H,W] f32.  The tile
@@ -315,7 +316,7 @@ class CellSegmentationInference:
             bin_am, typ_am = self.model._last_argmax              # argmax planes written by the forward kernels
             inst, recs, n_recs, contours, n_pts = postprocess_device(bin_am, typ_am, pred["hv_map"],
                                                                      self.model.num_nuclei_classes, obj, ks)
-            pooled, cap = pool_cell_tokens_fixed(pred["tokens"], recs, n_recs, self.model.patch_size)
+            pooled, cap = pool_cell_tokens_fixed(pred["tokens"], recs, n_recs, self.model.patch_size, cap=self.pool_cap)
             ev = torch.cuda.Event()
             ev.record()
             return ids, mds, recs, n_recs, contours, n_pts, pooled, cap, ev, pred["tokens"]
@@ -327,7 +328,7 @@ class CellSegmentationInference:
             check_capacity(recs, nr, contours, npt)
             if (nr > cap).any():                                   # rare: a tile with more cells than fixed pooling slots
                 exact, off = pool_cell_tokens(tokens, recs, n_recs, self.model.patch_size)
-                pooled = [exact[off[b]:off[b] + nr[b]] for b in range(len(ids))]
+                pooled = [exact[int(off[b]):int(off[b]) + int(nr[b])] for b in range(len(ids))]   # per-tile rows, as pooled[b] below
             mx_r, mx_p = int(nr.max()), int(npt.max())
             rec_h = recs[:, :mx_r].cpu().numpy().view(REC_DTYPE).reshape(len(ids), mx_r)
             pts_h = contours[:, :mx_p].cpu().numpy()
@@ -336,7 +337,7 @@ class CellSegmentationInference:
                 processed.append(f"{row}_{col}")
                 ir, fr, ct, keep = SlideCells.from_tile_records(rec_h[b, :nr[b]], pts_h[b], tile, row, col,
                                                                 nuclei_types["Background"], patch_size, overlap)
-                sel = torch.as_tensor(keep, dtype=torch.long, device=pooled.device)
+                sel = torch.as_tensor(keep, dtype=torch.long, device=pooled[b].device)
                 parts.append(SlideCells(ir, fr, ct, pooled[b].index_select(0, sel)))
             stats["tiles"] += len(ids)
 

@@ -175,10 +175,6 @@ class CellViT(nn.Module):
                                  extract_layers=tuple(extract_layers), num_nuclei_classes=num_nuclei_classes,
                                  num_tissue_classes=num_tissue_classes, mlp_ratio=int(mlp_ratio),
                                  regression_loss=regression_loss, pos_grid=14, name="CellViT")
-        if num_tissue_classes <= 0:
-            # reference: the tissue head degenerates to nn.Identity and `tissue_types` becomes the pooled embedding
-            # (vits_histo.py:339, cellvit.py:568-572) — not built here; fail loudly instead of returning garbage
-            raise NotImplementedError("cellvit_amd builds the tissue classification head: num_tissue_classes must be > 0")
         self.cfg = _cfg
         self.patch_size = 16
         self.num_tissue_classes = num_tissue_classes
@@ -312,7 +308,10 @@ class CellViT(nn.Module):
             dev = x.device
             f32 = dict(device=dev, dtype=torch.float32)
             out_t = {
-                "tissue_types": torch.empty((B, cfg.num_tissue_classes), **f32),
+                # num_tissue_classes == 0: the head is nn.Identity, `tissue_types` = the pooled embedding
+                # (vits_histo.py:359-362: [B, embed_dim]; cellvit.py:568-572: [B, neck channels])
+                "tissue_types": torch.empty((B, cfg.num_tissue_classes if cfg.num_tissue_classes > 0 else
+                                             (cfg.embed_dim if cfg.arch == ARCH_VIT else cfg.neck_chans)), **f32),
                 "nuclei_binary_map": torch.empty((B, 2, H, W), **f32),
                 "hv_map": torch.empty((B, 2, H, W), **f32),
                 "nuclei_type_map": torch.empty((B, cfg.num_nuclei_classes, H, W), **f32),

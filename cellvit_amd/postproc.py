@@ -248,6 +248,8 @@ def calculate_instances(pred_types: torch.Tensor, pred_insts: torch.Tensor) -> L
     B, H, W = pred_insts.shape
     typ = argmax_channels(pred_types.to(dev)) if pred_types.shape[1] > 1 else torch.zeros((B, H, W), device=dev, dtype=torch.uint8)
     nr_types = int(pred_types.shape[1])
+    if nr_types > 8:      # the type vote of k_inst_stats has 8 bins; the reference's np.unique has no limit (post_proc_cellvit.py:300-318)
+        raise NotImplementedError(f"calculate_instances: {nr_types} nucleus classes, the device type vote holds at most 8")
     e = _PPEngine.get(dev, B, H, W)
     if int(pred_insts.max()) > H * W // 16:
         raise CapacityError(f"instance ids above {H * W // 16} have no accumulator slot on a {H}x{W} tile: remap the labels first")
@@ -257,7 +259,7 @@ def calculate_instances(pred_types: torch.Tensor, pred_insts: torch.Tensor) -> L
         n_recs = torch.zeros((B,), device=dev, dtype=torch.int32)
         n_pts = torch.zeros((B,), device=dev, dtype=torch.int32)
         contours = torch.empty((B, e.max_pts, 2), device=dev, dtype=torch.int32)
-        _lib.check(e.lib.cv_pp_records(e.h, inst.data_ptr(), typ.data_ptr(), B, min(nr_types, 8), recs.data_ptr(),
+        _lib.check(e.lib.cv_pp_records(e.h, inst.data_ptr(), typ.data_ptr(), B, nr_types, recs.data_ptr(),
                                        n_recs.data_ptr(), contours.data_ptr(), n_pts.data_ptr(),
                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return records_to_dicts(recs, n_recs, contours, n_pts)

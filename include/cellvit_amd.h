@@ -65,7 +65,8 @@ typedef struct cv_config {
 /* Device buffers for the outputs of one forward call (fp32, contiguous, caller-allocated; NULL = skip).
  * Shapes follow the dict returned by CellViT.forward (cellvit.py:160-169).                            */
 typedef struct cv_outputs {
-    float* tissue_types;          /* [B, num_tissue_classes]                       */
+    float* tissue_types;          /* [B, num_tissue_classes]; num_tissue_classes == 0 (head = nn.Identity, vits_histo.py:359-362,
+                                     cellvit.py:568-572): the pooled embedding, [B, embed_dim] (ViT) / [B, neck_chans] (SAM) */
     float* nuclei_binary_map;     /* [B, 2, H, W]                                  */
     float* hv_map;                /* [B, 2, H, W]                                  */
     float* nuclei_type_map;       /* [B, num_nuclei_classes, H, W]                 */
@@ -79,6 +80,8 @@ const char* cv_last_error(void);
 /* 1 if the library was built with -DCVA_ABLATION (experiment switches CVA_* honoured, incl. work-skipping *_DBG
  * instantiations); 0 for the production build, which ignores the environment.  bench.py refuses ablation builds.   */
 int cv_build_is_ablation(void);
+/* The compiler flags this library was built with (cellvit_amd/build.py records them); bench.py prints them in its line. */
+const char* cv_build_flags(void);
 
 /* nn.Module construction — cellvit.py:57-151 / 514-572. */
 int cv_create(const cv_config* cfg, cv_handle** out);

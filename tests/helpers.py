@@ -16,6 +16,9 @@ CASES = {
     "samb_128": (lambda: cellvit_sam_config("SAM-B"), 2, 128, 128),
     "samh_256": (lambda: cellvit_sam_config("SAM-H"), 1, 256, 256),
     "samh_1024": (lambda: cellvit_sam_config("SAM-H"), 1, 1024, 1024),
+    "vit256_1024": (lambda: cellvit256_config(), 1, 1024, 1024),          # BASELINE.json configs[1] geometry (4097 tokens)
+    "vit256_nohead_64": (lambda: cellvit256_config(6, 0), 2, 64, 64),     # num_tissue_classes = 0: head = nn.Identity
+    "samb_nohead_64": (lambda: cellvit_sam_config("SAM-B", 6, 0), 2, 64, 64),
 }
 
 

@@ -12,6 +12,9 @@ import torch  # noqa: E402
 
 from cellvit_amd import _lib  # noqa: E402
 
+if os.environ.get("CVA_LIB") == "abl":      # the experiment flavour (python -m cellvit_amd.build --ablation): CVA_* switches honoured
+    _lib.LIB_PATH = os.path.join(ROOT, "cellvit_amd", "libcellvit_amd_abl.so")
+
 
 def main():
     M, N, K = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (16384, 5120, 1280)
@@ -56,7 +59,7 @@ def main():
         bad += int((out != first).sum().item())
     if bad:
         print(f"RACE: {bad} mismatching elements over {nrace} repeats")
-    print(f"CVA_GEMM={os.environ.get('CVA_GEMM', '1')} M={M} N={N} K={K}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s  maxerr {err:.3e}")
+    print(f"CVA_GEMM4={os.environ.get('CVA_GEMM4', '-')} ACT={act} RES={use_res} M={M} N={N} K={K}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s  maxerr {err:.3e}")
 
 
 if __name__ == "__main__":

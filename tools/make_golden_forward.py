@@ -30,7 +30,7 @@ def make_input(batch, h, w, first_tile=0):
     return torch.from_numpy(np.stack(xs))
 
 
-def run(name, model, cfg, batch, h, w, full=True, crop=64):
+def run(name, model, cfg, batch, h, w, full=True, crop=64, tok_crop=None):
     sd = make_state_dict(cfg, seed=0)
     print(name, model.load_state_dict(sd))
     model.eval()
@@ -46,7 +46,7 @@ def run(name, model, cfg, batch, h, w, full=True, crop=64):
             rec[k] = v
         else:  # large tile: keep a centre crop + corner crop + global statistics
             H, W = v.shape[-2:]
-            c = min(crop, H)
+            c = min(crop if (k != "tokens" or tok_crop is None) else tok_crop, H)
             y0, x0 = (H - c) // 2, (W - c) // 2
             rec[k + "_center"] = v[..., y0:y0 + c, x0:x0 + c].copy()
             rec[k + "_corner"] = v[..., :c, :c].copy()
@@ -60,7 +60,8 @@ def run(name, model, cfg, batch, h, w, full=True, crop=64):
 def main():
     os.makedirs(OUT, exist_ok=True)
     cv = ref_import.import_cellvit()
-    which = sys.argv[1:] or ["vit256_256", "vit256_b2_128x192", "samb_128", "samh_256", "samh_1024"]
+    which = sys.argv[1:] or ["vit256_256", "vit256_b2_128x192", "samb_128", "samh_256", "samh_1024", "vit256_1024",
+                             "vit256_nohead_64", "samb_nohead_64"]
     if "vit256_256" in which:   # BASELINE.json configs[0]
         run("vit256_256", cv.CellViT256(None, 6, 19), cellvit256_config(), 1, 256, 256)
     if "vit256_b2_128x192" in which:   # batch > 1, non-square (bicubic pos-embed w/h handling)
@@ -72,6 +73,12 @@ def main():
     if "samh_1024" in which:    # BASELINE.json configs[2] shape; crops + statistics only
         run("samh_1024", cv.CellViTSAM(None, 6, 19, "SAM-H"), cellvit_sam_config("SAM-H"), 1, 1024, 1024,
             full=False)
+    if "vit256_1024" in which:  # BASELINE.json configs[1] shape (4097 tokens); crops + statistics only
+        run("vit256_1024", cv.CellViT256(None, 6, 19), cellvit256_config(), 1, 1024, 1024, full=False, tok_crop=16)
+    if "vit256_nohead_64" in which:   # num_tissue_classes = 0: head = nn.Identity, tissue_types = norm(x)[:, 0]
+        run("vit256_nohead_64", cv.CellViT256(None, 6, 0), cellvit256_config(6, 0), 2, 64, 64)
+    if "samb_nohead_64" in which:     # num_tissue_classes = 0: tissue_types = mean of the neck output
+        run("samb_nohead_64", cv.CellViTSAM(None, 6, 0, "SAM-B"), cellvit_sam_config("SAM-B", 6, 0), 2, 64, 64)
 
 
 if __name__ == "__main__":
