@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--allow-debug-env", action="store_true", help="run although CVA_* experiment switches are set (recorded in config)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f8"],
                     help="f8: CDNA4 MX-fp8 MFMA for the encoder's linear layers, fp16 attention core and decoder (BASELINE.json configs[4])")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the short extra legs after the timed region (fp8 engine, CellViT-256, slide-level CLI run)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run post-processing on the forward stream instead of a second HIP stream")
     return ap.parse_args()
@@ -105,6 +107,71 @@ def cpu_baseline(cfg, sd, tile, cells, with_8_threads=True):
         t8 = time.perf_counter() - t0
         torch.set_num_threads(n_all)
         out["threads8"] = {"value": 1.0 / (t8 + t_pp), "unit": "tiles/s", "cores": 8, "forward_s": t8}
+    return out
+
+
+def extras(model, step, B, dev):
+    """Short legs OUTSIDE the timed region, so that the driver's one default line also carries (a) the fp8 engine
+    (BASELINE.json configs[4]), (b) CellViT-256 (configs[1] + post-processing) and (c) the slide-level CLI route (configs[3]: PNG
+    decode -> forward -> post-processing -> pooling -> records -> exchange -> de-duplication -> writers) with real cell counts.
+    Same step function / same batch as the headline for (a); 3 timed steps each."""
+    import importlib.util
+    import numpy as np
+    import torch
+    from cellvit_amd.model import CellViT256
+    from cellvit_amd.postproc import postprocess_device
+    from cellvit_amd.spec import cellvit256_config
+    from cellvit_amd.synth import synth_nuclei_maps
+    from cellvit_amd.weights import make_state_dict, synthetic_tile_u8
+    out = {}
+
+    def timed(fn, n=3, w=2):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    try:
+        model.compute_dtype = "fp8"
+        out["fp8_tiles_per_s"] = B / timed(step)
+        out["fp8_note"] = "MX-fp8 qkv/fc1/fc2 + fp16 attention core/proj/decoder, same step (forward + post-processing) and batch as the headline"
+    except Exception as e:      # noqa: BLE001
+        out["fp8_error"] = repr(e)[:200]
+    finally:
+        model.compute_dtype = "fp16"
+    try:
+        m2 = CellViT256(None, 6, 19, compute_dtype="fp16")
+        m2.load_state_dict(make_state_dict(cellvit256_config(), seed=0))
+        x2 = torch.from_numpy(np.stack([synthetic_tile_u8(i, size=1024, he_like=True) for i in range(B)])).to(dev)
+        maps = [synth_nuclei_maps(i, 1024, 800) for i in range(min(B, 8))]
+        rep = (B + len(maps) - 1) // len(maps)
+        pb = torch.from_numpy(np.stack([m[1] for m in maps])).to(dev).repeat(rep, 1, 1)[:B]
+        pt = torch.from_numpy(np.stack([m[0] for m in maps])).to(dev).repeat(rep, 1, 1)[:B]
+        ph = torch.from_numpy(np.stack([m[2] for m in maps])).to(dev).repeat(rep, 1, 1, 1)[:B]
+
+        def step2():
+            m2.forward_u8(x2, (0.5,) * 3, (0.5,) * 3, retrieve_tokens=True)
+            postprocess_device(pb, pt, ph, 6, 10, 21, want_contours=True)
+        out["vit256_tiles_per_s"] = B / timed(step2)
+        out["vit256_note"] = "CellViT-256 fp16, 1024^2 tiles, forward + on-GPU post-processing (BASELINE.json configs[1] + post-processing)"
+        del m2, x2, pb, pt, ph
+    except Exception as e:      # noqa: BLE001
+        out["vit256_error"] = repr(e)[:200]
+    try:
+        spec = importlib.util.spec_from_file_location("bench_slide", os.path.join(ROOT, "tools", "bench_slide.py"))
+        bs = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bs)
+        r = bs.run(tiles=144, batch=16, model="samh", real_model=model)
+        out["slide"] = {k: r[k] for k in ("tiles", "batch", "ranks", "tile_loop_tiles_per_s_rank0", "cells_written", "margin_records",
+                                          "margin_kept", "exchange_s", "stitch_s", "to_dicts_s", "write_s", "slide_total_s",
+                                          "slide_tiles_per_s", "output_MB")}
+        out["slide_note"] = ("tools/bench_slide.py on a 12 x 12-tile synthetic slide (BASELINE.json configs[3] route on one GPU): the forward runs "
+                             "for real, its planes are replaced by crops of a periodic synthetic nucleus world (~800 cells per tile)")
+    except Exception as e:      # noqa: BLE001
+        out["slide_error"] = repr(e)[:300]
     return out
 
 
@@ -276,17 +343,21 @@ def main():
                                     "frac": fl[i] / (ms[i] * 1e-3) / 1e12 / KPEAK[i]}
             dom = max(range(NK), key=lambda i: ms[i])
             ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
-            traffic = None
+            traffic, tprov = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic_latest.json" if args.dtype == "f16" else "traffic_f8.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(KCLASS[dom])
+                    tj = json.load(open(tpath))
+                    traffic = tj.get(KCLASS[dom])
+                    import hashlib
+                    tprov = {"file_sha16": hashlib.sha256(open(tpath, "rb").read()).hexdigest()[:16], "tiles_per_step_of_the_pmc_run": tj.get("tiles_per_step"),
+                             "collected_at_commit": tj.get("commit"), "matches_this_run": tj.get("tiles_per_step") == B}
                 except Exception:
                     traffic = None
             roofline = {"bound": "mfma", "kernel": KCLASS[dom], "achieved": ach, "peak": KPEAK[dom],
                         "unit": "TFLOP/s", "frac": ach / KPEAK[dom],
                         "flops_per_launch": fl[dom] / n[dom], "avg_launch_us": 1e3 * ms[dom] / n[dom],
-                        "launches": int(n[dom]), "traffic": traffic,
+                        "launches": int(n[dom]), "traffic": traffic, "traffic_provenance": tprov,
                         "traffic_source": os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, "
                                           "corrected per MI355X_MICROARCH.md (tools/pmc_traffic.py); not collected in this run"
                                           if traffic is not None else None}
@@ -298,6 +369,7 @@ def main():
                        "parallelism": f"tile-sharded x{world}, no data-path collective",
                        "input": "raw uint8 HWC tiles resident in HBM; inference transform fused into the forward (cv_forward_u8)",
                        "experiment_env": dbg + (["ABLATION_BUILD"] if _lib.load().cv_build_is_ablation() else []),
+                       "library": os.path.relpath(_lib.LIB_PATH, ROOT), "library_build_flags": (_lib.load().cv_build_flags() or b"").decode(),
                        "postproc": bool(do_pp), "postproc_stream_overlap": bool(overlap), "postproc_input": f"synthetic nuclei maps, {args.cells} cells/tile",
                        "instances_per_step": n_inst},
             "stage_ms_sequential": {"forward": fwd_ms, "postproc": pp_ms},
@@ -310,6 +382,8 @@ def main():
             "roofline": roofline,
             "kernel_classes": kstats,
         }
+        if world == 1 and not args.no_extras and args.model == "samh" and args.dtype == "f16" and T == 1024:
+            rec["extra"] = extras(model, step, B, dev)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, sd, T, args.cells)
         print(json.dumps(rec))

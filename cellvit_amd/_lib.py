@@ -88,6 +88,11 @@ SYMBOLS.update({
     "cv_pp_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
     "cv_pp_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "cv_stitch_overlaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.POINTER(C.c_int32), C.c_void_p]),
+    "cv_write_cells_json": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int] + [C.c_void_p] * 11),
+    "cv_stitch_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.POINTER(C.c_int32), C.c_void_p]),
 })
 
 

@@ -1086,10 +1086,26 @@ extern "C" int cv_op_conv3x3(int dtype, const void* src1, int C1, const void* sr
                              void* stream) {
     const int pe = dtype == CV_DTYPE_F16 ? 8 : 4;
     const int K = 9 * (C1 + C2);
-    if (C1 % pe || C2 % pe || K % bk_of(dtype)) { cva_set_error("cv_op_conv3x3: channels %% %d, 9*C %% %d required", pe, bk_of(dtype)); return CV_ERR_INVALID; }
+    if (C1 % pe || C2 % pe) { cva_set_error("cv_op_conv3x3: channels %% %d required", pe); return CV_ERR_INVALID; }
     ConvW w; w.W = const_cast<void*>(Wk); w.bias = const_cast<float*>(bias); w.Cout = Cout; w.Ctot = C1 + C2; w.K = K; w.Cin_real = C1 + C2;
     w.ldw = K; w.relu = relu;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (K % bk_of(dtype)) {
+        // filter rows are read in whole tile rows: as pack_conv3 does for the model's layers (e.g. CellViT-256's 312-channel
+        // bottleneck), give them a zero-padded row pitch — a copy on the caller's stream into a grow-only scratch buffer
+        static void* padded = nullptr; static size_t padded_bytes = 0;
+        const size_t es = dtype == CV_DTYPE_F16 ? 2 : 4;
+        const int ldw = round_up(K, bk_of(dtype));
+        const size_t need = (size_t)Cout * ldw * es;
+        if (need > padded_bytes) {
+            if (padded) { CVA_CHECK_HIP(hipDeviceSynchronize()); CVA_CHECK_HIP(hipFree(padded)); padded = nullptr; padded_bytes = 0; }
+            CVA_CHECK_HIP(hipMalloc(&padded, need));
+            padded_bytes = need;
+        }
+        CVA_CHECK_HIP(hipMemsetAsync(padded, 0, need, st));
+        CVA_CHECK_HIP(hipMemcpy2DAsync(padded, (size_t)ldw * es, Wk, (size_t)K * es, (size_t)K * es, Cout, hipMemcpyDeviceToDevice, st));
+        w.W = padded; w.ldw = ldw;
+    }
     if (dtype != CV_DTYPE_F16) return run_conv3<float>(src1, C1, src2, C2, w, out, out_f32, B, H, W, st);
     // as cv_finalize does for the model's layers: a second copy of the filter in the K order of the implicit-GEMM path, rebuilt
     // on the caller's stream at every call into a grow-only scratch buffer (no allocation / synchronisation per call)

@@ -85,6 +85,9 @@ int launch_gemm8(const GemmParams& p, hipStream_t stream);
 // per gemm4_takes.  sched: slot placement variant (ablation builds; production = 1).
 bool gemm4_takes(const GemmParams& p);
 int launch_gemm4(const GemmParams& p, int sched, hipStream_t stream);
+// gemm2.hip: 256 x 128 tiles, two unsynchronised workgroups per CU (OUT_LINEAR).
+bool gemm2_supported(const GemmParams& p);
+int launch_gemm2(const GemmParams& p, hipStream_t stream);
 // fp8 engine: the same kernel on MX-fp8 operands; out_mode OUT_LINEAR (fp32 / fp16 out, optional residual), OUT_QKV or
 // OUT_MX8.  Returns hipErrorInvalidValue when the shape does not qualify (there is no fallback kernel for fp8 operands).
 bool gemm8_f8_supported(const GemmParams& p);

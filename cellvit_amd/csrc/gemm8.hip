@@ -607,6 +607,8 @@ int launch_gemm8(const GemmParams& p, hipStream_t stream) {
 #ifdef CVA_ABLATION
     {   // experiment (ablation builds): CVA_GEMM4 = 10 + s runs the one-wave-per-SIMD kernel of gemm4.hip with slot placement s, 30 + a its
         // work-skipping instantiations.  Measured slower than this kernel (profiles/r03_exp_gemm4.txt), so production never routes there.
+        static const int g2 = cva_env_int("CVA_GEMM2", 0);
+        if (g2 && !(p.dbg & 7) && gemm2_supported(p)) return launch_gemm2(p, stream);
         static const int g4 = cva_env_int("CVA_GEMM4", 0);
         if (g4 >= 10 && !(p.dbg & 7) && gemm4_takes(p)) return launch_gemm4(p, g4 - 10, stream);
     }

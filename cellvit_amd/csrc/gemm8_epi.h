@@ -51,9 +51,10 @@ __device__ __forceinline__ float gelu_as(float x) {
 // GELU on the 8-phase path: x * Phi(x) with Phi linearly interpolated in the LDS table (h = 1/128: |dPhi| <= h^2/8 |x phi(x)|
 // < 1.9e-6 absolute and < 2e-4 relative everywhere, i.e. below half an fp16 ulp of the result); 8 full-rate VALU + one
 // ds_read2_b32 per element instead of 12 + rcp + exp.  x <= -8 -> x * 6e-16, x >= 8 -> x.
+template <int PER_UNIT = 128>     // table entries per unit of x; the table spans x = -8 .. 8 (16 * PER_UNIT + 1 entries)
 __device__ __forceinline__ float gelu_lut(float x, const float* lut) {
-    float u = fmaf(x, 128.f, 1024.f);
-    u = __builtin_amdgcn_fmed3f(u, 0.f, 2047.999f);
+    float u = fmaf(x, (float)PER_UNIT, 8.f * PER_UNIT);
+    u = __builtin_amdgcn_fmed3f(u, 0.f, 16.f * PER_UNIT - 0.001f);
     const float fr = __builtin_amdgcn_fractf(u);
     const int i = (int)u;
     const float t0 = lut[i], t1 = lut[i + 1];
@@ -63,7 +64,7 @@ __device__ __forceinline__ float gelu_lut(float x, const float* lut) {
 // Direct epilogue for the TRANSPOSED accumulator orientation (C^T fragments: lane (g, li) holds, for row
 // m = i*16 + li of the wave block, the 16 CONSECUTIVE columns g*16 .. g*16+15 — the W rows are permuted at DMA
 // time to make them consecutive).  No LDS: bias / activation / residual on registers, 16-byte stores.
-template <int OMODE>
+template <int OMODE, int LUT_PER_UNIT = 128>
 __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&acc)[8][4], const float (&bv)[16],
                                                  const int mrow0, const int ncol0, const int lane, const float* lut) {
     const int g = lane >> 4, li = lane & 15;
@@ -96,7 +97,7 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[j * 4 + r] = gelu_lut(acc[i][j][r] + bv[j * 4 + r], lut);
+                for (int r = 0; r < 4; ++r) v[j * 4 + r] = gelu_lut<LUT_PER_UNIT>(acc[i][j][r] + bv[j * 4 + r], lut);
         } else if (p.act == ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)

@@ -1,0 +1,104 @@
+// Native writers of the slide-level outputs (reference: json.dump of per-cell dicts,
+// cell_segmentation/inference/cell_detection.py:438-457).  The reference serialises ~10^6 Python dicts per slide through the
+// pure-Python JSON encoder (indent=2): tens of seconds and gigabytes per slide — with the tile loop on 8 GPUs that is the whole
+// wall-clock.  Here the files are rendered from the packed record arrays by host code in this library (no Python object per
+// cell; called through ctypes, so the GIL is released and cells.pt is pickled concurrently).  Same JSON documents: same keys
+// in the same order, same values (doubles with 17 significant digits: they parse to the identical binary64), one cell per line.
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/cellvit_amd.h"
+
+void cva_set_error(const char* fmt, ...);
+
+namespace {
+
+struct Out {
+    FILE* f;
+    std::vector<char> buf;
+    bool ok = true;
+    explicit Out(FILE* f_) : f(f_) { buf.reserve(1 << 22); }
+    void flush() {
+        if (!buf.empty()) { if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) ok = false; buf.clear(); }
+    }
+    void put(const char* s, size_t n) { buf.insert(buf.end(), s, s + n); if (buf.size() > (1u << 22) - 4096) flush(); }
+    void put(const char* s) { put(s, strlen(s)); }
+    void i64(long long v) { char t[24]; const int n = snprintf(t, sizeof t, "%lld", v); put(t, n); }
+    void f64(double v) {
+        char t[40];
+        int n = snprintf(t, sizeof t, "%.17g", v);
+        // JSON numbers as Python writes floats: always with a fraction or exponent ("3.0", not "3")
+        bool plain = true;
+        for (int k = 0; k < n; ++k) if (t[k] == '.' || t[k] == 'e' || t[k] == 'n' || t[k] == 'i') { plain = false; break; }
+        if (plain) { t[n++] = '.'; t[n++] = '0'; }
+        put(t, n);
+    }
+};
+
+// get_edge_patch (cell_detection.py:877-902): [top, right, down, left] -> neighbour tile offsets (drow, dcol), or none
+const int8_t EDGE_TABLE[16][7] = {   // n, then up to 3 (dr, dc) pairs; index = top*8 + right*4 + down*2 + left
+    {-1}, {1, 0, -1}, {1, 1, 0}, {3, 1, 0, 1, -1, 0, -1}, {1, 0, 1}, {-1}, {3, 0, 1, 1, 1, 1, 0}, {-1},
+    {1, -1, 0}, {3, 0, -1, -1, -1, -1, 0}, {-1}, {-1}, {3, -1, 0, -1, 1, 0, 1}, {-1}, {-1}, {-1}};
+
+}  // namespace
+
+extern "C" int cv_write_cells_json(const char* path, const char* header, int detection_only, int n, const int64_t* bbox,
+                                   const double* centroid, const int64_t* ct_off, const int64_t* ct_xy, const double* type_prob,
+                                   const int32_t* type, const int32_t* patch_rc, const int32_t* status, const int64_t* offset_global,
+                                   const uint8_t* edge, const uint8_t* edge_pos) {
+    if (!path || !header || n < 0 || (n && (!bbox || !centroid || !type))) { cva_set_error("cv_write_cells_json: bad argument"); return CV_ERR_INVALID; }
+    if (!detection_only && n && (!ct_off || !ct_xy || !type_prob || !patch_rc || !status || !offset_global || !edge || !edge_pos)) {
+        cva_set_error("cv_write_cells_json: bad argument"); return CV_ERR_INVALID;
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) { cva_set_error("cv_write_cells_json: cannot open %s", path); return CV_ERR_INVALID; }
+    Out o(f);
+    o.put("{");
+    o.put(header);                                   // '"wsi_metadata": {...}, "processed_patches": [...], "type_map": {...}' rendered by the caller
+    o.put(", \"cells\": [");
+    for (int k = 0; k < n; ++k) {
+        o.put(k ? ",\n{\"bbox\": [[" : "\n{\"bbox\": [[");
+        o.i64(bbox[4 * k]); o.put(", "); o.i64(bbox[4 * k + 1]); o.put("], ["); o.i64(bbox[4 * k + 2]); o.put(", "); o.i64(bbox[4 * k + 3]);
+        o.put("]], \"centroid\": ["); o.f64(centroid[2 * k]); o.put(", "); o.f64(centroid[2 * k + 1]); o.put("]");
+        if (detection_only) {
+            o.put(", \"type\": "); o.i64(type[k]); o.put("}");
+            continue;
+        }
+        o.put(", \"contour\": [");
+        for (int64_t q = ct_off[k]; q < ct_off[k + 1]; ++q) {
+            o.put(q == ct_off[k] ? "[" : ", ["); o.i64(ct_xy[2 * q]); o.put(", "); o.i64(ct_xy[2 * q + 1]); o.put("]");
+        }
+        o.put("], \"type_prob\": "); o.f64(type_prob[k]);
+        o.put(", \"type\": "); o.i64(type[k]);
+        o.put(", \"patch_coordinates\": ["); o.i64(patch_rc[2 * k]); o.put(", "); o.i64(patch_rc[2 * k + 1]);
+        o.put("], \"cell_status\": "); o.i64(status[k]);
+        o.put(", \"offset_global\": ["); o.i64(offset_global[2 * k]); o.put(", "); o.i64(offset_global[2 * k + 1]); o.put("]");
+        if (edge[k]) {
+            const uint8_t* ps = edge_pos + 4 * k;
+            o.put(", \"edge_position\": true, \"edge_information\": {\"position\": [");
+            o.i64(ps[0]); o.put(", "); o.i64(ps[1]); o.put(", "); o.i64(ps[2]); o.put(", "); o.i64(ps[3]);
+            o.put("], \"edge_patches\": ");
+            const int8_t* e = EDGE_TABLE[(ps[0] & 1) * 8 + (ps[1] & 1) * 4 + (ps[2] & 1) * 2 + (ps[3] & 1)];
+            if (e[0] < 0) o.put("null");
+            else {
+                o.put("[");
+                for (int q = 0; q < e[0]; ++q) {
+                    o.put(q ? ", [" : "["); o.i64(patch_rc[2 * k] + e[1 + 2 * q]); o.put(", "); o.i64(patch_rc[2 * k + 1] + e[2 + 2 * q]); o.put("]");
+                }
+                o.put("]");
+            }
+            o.put("}}");
+        } else {
+            o.put(", \"edge_position\": false}");
+        }
+    }
+    o.put(n ? "\n]}" : "]}");
+    o.flush();
+    const bool ok = o.ok && fclose(f) == 0;
+    if (!ok) { cva_set_error("cv_write_cells_json: write to %s failed", path); return CV_ERR_INVALID; }
+    return CV_OK;
+}

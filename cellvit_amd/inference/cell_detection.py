@@ -191,29 +191,52 @@ class SlideCells:
         tok = self.tokens[torch.as_tensor(idx, dtype=torch.long, device=self.tokens.device)] if self.tokens is not None else None
         return SlideCells(self.ir[idx], self.fr[idx], ct, tok)
 
-    def to_dicts(self, patch_size: int, downsampling: float, overlap: int) -> List[dict]:
-        """Cell dicts of `cells.json` in global slide coordinates (cell_detection.py:341-391)."""
+    def geometry(self, patch_size: int, downsampling: float, overlap: int) -> dict:
+        """The slide-coordinate arrays of every cell (cell_detection.py:341-391), computed on the whole arrays:
+        bbox i64 [n,4] (rows += x_global, cols += y_global), centroid f64 [n,2] and contour i64 [m,2] ((x, y) += flipped
+        offset), contour offsets i64 [n+1], offset_global i64 [n,2], edge u8 [n], edge position u8 [n,4] (get_cell_position)."""
+        from .stitch import tile_offsets
+        n = len(self.ir)
+        ir, fr = self.ir, self.fr
         offs, lens = self.contour_slices()
+        xg, yg = tile_offsets(ir[:, S.I_ROW], ir[:, S.I_COL], patch_size, downsampling, overlap)
+        off = np.stack([xg, yg], 1).reshape(n, 2)                       # `offset_global` = [x_global, y_global] (:351)
+        bbox_t = ir[:, S.I_RMIN:S.I_CMAX + 1].astype(np.int64)
+        rep = np.repeat(np.arange(n), lens)
+        ct_off = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=ct_off[1:])
+        return {
+            "bbox": np.ascontiguousarray(bbox_t + np.concatenate([off, off], 1)),
+            "centroid": np.ascontiguousarray(fr[:, [S.F_CX, S.F_CY]] + off[:, ::-1]),   # (x, y): + flip(offset) (:352-353)
+            "contour": np.ascontiguousarray(self.ct.astype(np.int64).reshape(-1, 2) + off[rep][:, ::-1]),
+            "ct_off": ct_off, "offset_global": np.ascontiguousarray(off),
+            "edge": np.ascontiguousarray((ir[:, S.I_EDGE] != 0).astype(np.uint8)),
+            "edge_pos": np.ascontiguousarray(np.stack([bbox_t[:, 0] == 0, bbox_t[:, 3] == patch_size, bbox_t[:, 2] == patch_size,
+                                                       bbox_t[:, 1] == 0], 1).astype(np.uint8)),       # get_cell_position (:787-817)
+        }
+
+    def to_dicts(self, patch_size: int, downsampling: float, overlap: int) -> List[dict]:
+        """Cell dicts of `cells.json` in global slide coordinates (cell_detection.py:341-391).  The arithmetic runs on the
+        whole arrays (`geometry`); the per-cell work is one dict literal over pre-converted Python lists."""
+        n = len(self.ir)
+        if n == 0:
+            return []
+        ir, fr = self.ir, self.fr
+        g = self.geometry(patch_size, downsampling, overlap)
+        bbox = g["bbox"].reshape(n, 2, 2).tolist()
+        cent, ctg = g["centroid"].tolist(), g["contour"].tolist()
+        prob, typ = fr[:, S.F_PROB].tolist(), ir[:, S.I_TYPE].tolist()
+        rows, cols, status = ir[:, S.I_ROW].tolist(), ir[:, S.I_COL].tolist(), ir[:, S.I_STATUS].tolist()
+        edge = g["edge"].astype(bool).tolist()
+        off_l, offs_l = g["offset_global"].tolist(), g["ct_off"].tolist()
+        pos = g["edge_pos"].astype(np.int64).tolist()
         out = []
-        for k in range(len(self.ir)):
-            i, f = self.ir[k], self.fr[k]
-            row, col = int(i[S.I_ROW]), int(i[S.I_COL])
-            xg, yg = S.global_offset(row, col, patch_size, downsampling, overlap)
-            off = np.array([xg, yg])
-            bbox = np.array([[i[S.I_RMIN], i[S.I_CMIN]], [i[S.I_RMAX], i[S.I_CMAX]]])
-            d = {
-                "bbox": (bbox + off).tolist(),
-                "centroid": (f[[S.F_CX, S.F_CY]] + np.flip(off)).tolist(),
-                "contour": (self.ct[offs[k]:offs[k] + lens[k]] + np.flip(off)).tolist(),
-                "type_prob": float(f[S.F_PROB]), "type": int(i[S.I_TYPE]),
-                "patch_coordinates": [row, col],
-                "cell_status": int(i[S.I_STATUS]),
-                "offset_global": off.tolist(),
-            }
-            if i[S.I_EDGE]:
-                pos = S.cell_edge_position(bbox, patch_size)
+        for k in range(n):
+            d = {"bbox": bbox[k], "centroid": cent[k], "contour": ctg[offs_l[k]:offs_l[k + 1]], "type_prob": prob[k], "type": typ[k],
+                 "patch_coordinates": [rows[k], cols[k]], "cell_status": status[k], "offset_global": off_l[k]}
+            if edge[k]:
                 d["edge_position"] = True
-                d["edge_information"] = {"position": pos, "edge_patches": S.edge_patches(pos, row, col)}
+                d["edge_information"] = {"position": pos[k], "edge_patches": S.edge_patches(pos[k], rows[k], cols[k])}
             else:
                 d["edge_position"] = False
             out.append(d)
@@ -221,16 +244,25 @@ class SlideCells:
 
 
 def finalize_slide(local: SlideCells, patch_size: int, downsampling: float, overlap: int, device=None,
-                   logger: Optional[logging.Logger] = None) -> Tuple[SlideCells, List[dict]]:
+                   logger: Optional[logging.Logger] = None, compute_device=None,
+                   timings: Optional[dict] = None, want_dicts: bool = True) -> Tuple[SlideCells, Optional[List[dict]]]:
     """Slide-level step after the tile loop (cell_detection.py:423-433), identical for any world size:
       1. every rank contributes ONLY its margin-cell records (status != 0) to one all-gatherv
          (`sharding.all_gather_margin_records`: RCCL over xGMI with device buffers, gloo on CPU);
-      2. the gathered records are put in slide order (tile index) and ONE global `stitch_cells` runs — the same
-         deterministic computation on every rank, so no second collective is needed;
+      2. the gathered records are put in slide order (tile index) and ONE global de-duplication runs on the packed arrays
+         (`stitch.stitch_margin_records`: candidate pairs + exact polygon intersections on the GPU, the greedy rounds in the
+         library's host code) — the same deterministic computation on every rank, so no second collective is needed;
       3. each rank keeps its mid cells + its surviving margin cells; the survivors of all ranks are then gathered
          in slide order for the single writer (rank 0).
-    Returns (all kept cells of the slide in slide order, their dicts) — complete on every rank."""
+    Every collective is entered by every rank, whatever it holds (a rank may have received no tile at all).
+    `device`: where the exchange buffers live (cuda under nccl, cpu under gloo); `compute_device`: where the geometry of the
+    de-duplication runs (default: `device`).  `timings` (optional dict) receives the seconds of exchange / stitch / dicts.
+    Returns (all kept cells of the slide in slide order, their dicts or None with want_dicts=False) — complete on every
+    rank.  Nothing on this path needs per-cell dicts: the writers render the files from the arrays (`write_outputs`)."""
+    import time
     import torch.distributed as dist
+    from .stitch import stitch_margin_records
+    t_start = time.perf_counter()
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     dev = device or torch.device("cpu")
@@ -238,21 +270,24 @@ def finalize_slide(local: SlideCells, patch_size: int, downsampling: float, over
     m_idx = np.nonzero(is_margin)[0]
     margin = local.select(m_idx)
     margin.tokens = None
-    # uid of a cell = (tile, id): instance ids are unique per tile
     gi, gf, gc = S.all_gather_margin_records(margin.ir, margin.fr, margin.ct, device=dev)
     perm = S.canonical_order(gi)
     gi, gf, gc = S.reorder_records(gi, gf, gc, perm)
-    g = SlideCells(gi, gf, gc)
-    g_dicts = g.to_dicts(patch_size, downsampling, overlap)
-    keep_g = stitch_cells(g_dicts, logger)                       # indices into the global margin list (all status != 0)
-    kept_uid = {(int(gi[k, S.I_TILE]), int(gi[k, S.I_ID])) for k in keep_g}
-    keep_local = np.array([k for k in range(len(local))
-                           if not is_margin[k] or (int(local.ir[k, S.I_TILE]), int(local.ir[k, S.I_ID])) in kept_uid],
-                          dtype=np.int64)
+    t_gather = time.perf_counter()
+    keep_g = stitch_margin_records(gi, gc, patch_size, downsampling, overlap, device=compute_device or dev, logger=logger)
+    t_stitch = time.perf_counter()
+    # uid of a cell = (tile, id): instance ids are unique per tile
+    uid = lambda ir: ir[:, S.I_TILE].astype(np.int64) * (1 << 32) + ir[:, S.I_ID].astype(np.int64)   # noqa: E731
+    keep_local = np.nonzero(~is_margin | np.isin(uid(local.ir), uid(gi[keep_g])))[0].astype(np.int64)
     mine = local.select(keep_local)
     if world > 1:
         ai, af, ac = S.all_gather_margin_records(mine.ir, mine.fr, mine.ct, device=dev)   # the writer's gather (same packed format)
-        tok = S.all_gather_rows(mine.tokens.to(dev)) if mine.tokens is not None else None
+        # token rows: the width is agreed first, ranks without cells contribute [0, D]
+        D = max(S.all_gather_int(int(mine.tokens.shape[1]) if mine.tokens is not None else 0, dev))
+        tok = None
+        if D > 0:
+            t_loc = mine.tokens if mine.tokens is not None else torch.zeros((0, D), dtype=torch.float32)
+            tok = S.all_gather_rows(t_loc.to(dev).float())
         perm = S.canonical_order(ai)
         ai, af, ac = S.reorder_records(ai, af, ac, perm)
         if tok is not None:
@@ -263,7 +298,13 @@ def finalize_slide(local: SlideCells, patch_size: int, downsampling: float, over
         allc = mine.select(perm)
     if logger:
         logger.info(f"[rank {rank}] cells after cleaning: {len(allc)} (margin cells exchanged: {len(gi)})")
-    return allc, allc.to_dicts(patch_size, downsampling, overlap)
+    t_collect = time.perf_counter()
+    dicts = allc.to_dicts(patch_size, downsampling, overlap) if want_dicts else None
+    if timings is not None:
+        timings.update({"margin_records": int(len(gi)), "margin_kept": int(len(keep_g)),
+                        "exchange_s": (t_gather - t_start) + (t_collect - t_stitch), "stitch_s": t_stitch - t_gather,
+                        "to_dicts_s": time.perf_counter() - t_collect})
+    return allc, dicts
 
 
 class CellSegmentationInference:
@@ -368,16 +409,21 @@ class CellSegmentationInference:
         self.logger.info(f"[rank {rank}/{world}] {stats['tiles']} tiles in {stats['t_loop']:.2f} s "
                          f"({stats['tiles'] / max(stats['t_loop'], 1e-9):.1f} tiles/s), cells before cleaning: {len(local)}")
         exch_dev = self.device if (dd and dist.get_backend() == "nccl") else torch.device("cpu")
-        allc, cells_all = finalize_slide(local, wsi.metadata["patch_size"], wsi.metadata["downsampling"], overlap,
-                                         device=exch_dev, logger=self.logger)
+        timings: dict = {}
+        allc, _ = finalize_slide(local, wsi.metadata["patch_size"], wsi.metadata["downsampling"], overlap,
+                                 device=exch_dev, logger=self.logger, compute_device=self.device, timings=timings, want_dicts=False)
         if world > 1:
             gathered: List[Optional[list]] = [None] * world
             dist.all_gather_object(gathered, processed)       # tile names only (a few bytes per tile)
             order = {f"{m['row']}_{m['col']}": i for i, m in enumerate(wsi.all_patch_metadata[n] for n in wsi.patches_list)}
             processed = sorted((p for part in gathered for p in part), key=lambda k: order.get(k, 1 << 30))
+        import time
+        t0 = time.perf_counter()
         if rank == 0:
-            write_outputs(outdir, wsi.metadata, processed, nuclei_types, allc, cells_all, geojson)
-        stats.update({"n_cells": len(cells_all), "outdir": str(outdir)})
+            write_outputs(outdir, wsi.metadata, processed, nuclei_types, allc, geojson, wsi.metadata["patch_size"],
+                          wsi.metadata["downsampling"], overlap)
+        timings["write_s"] = time.perf_counter() - t0
+        stats.update({"n_cells": len(allc), "cells_before_cleaning": len(local), "outdir": str(outdir), **timings})
         return stats
 
 
@@ -400,28 +446,53 @@ def pool_cell_tokens_fixed(tokens: torch.Tensor, recs: torch.Tensor, n_recs: tor
 
 
 def write_outputs(outdir: Path, wsi_metadata: dict, processed: List[str], nuclei_types: dict, allc: SlideCells,
-                  cells_all: List[dict], geojson: bool) -> None:
-    """The writers of cell_detection.py:438-475: cells.json, cell_detection.json, optional geojson pair, cells.pt."""
+                  geojson: bool, patch_size: int, downsampling: float, overlap: int) -> None:
+    """The writers of cell_detection.py:438-475: cells.json, cell_detection.json, optional geojson pair, cells.pt.
+    The two JSON files are rendered from the arrays by the library's host code (`cv_write_cells_json`, called through ctypes:
+    the GIL is released) while this thread pickles cells.pt; per-cell dicts exist only for the optional geojson pair."""
+    import ctypes as C
+    import threading
+    from .. import _lib
     from ..datamodel import make_cell_graph
+    lib = _lib.load()
+    n = len(allc)
+    g = allc.geometry(patch_size, downsampling, overlap)
     meta = {"wsi_metadata": wsi_metadata, "processed_patches": processed, "type_map": nuclei_types}
-    with open(outdir / "cells.json", "w") as f:
-        json.dump({**meta, "cells": cells_all}, f, indent=2, default=_np_default)
-    det = [{"bbox": c["bbox"], "centroid": c["centroid"], "type": c["type"]} for c in cells_all]
-    with open(outdir / "cell_detection.json", "w") as f:
-        json.dump({**meta, "cells": det}, f, indent=2, default=_np_default)
+    header = json.dumps(meta, default=_np_default)[1:-1].encode("utf-8")           # members without the outer braces
+    typ = np.ascontiguousarray(allc.ir[:, S.I_TYPE].astype(np.int32))
+    prob = np.ascontiguousarray(allc.fr[:, S.F_PROB].astype(np.float64))
+    rc = np.ascontiguousarray(allc.ir[:, [S.I_ROW, S.I_COL]].astype(np.int32))
+    status = np.ascontiguousarray(allc.ir[:, S.I_STATUS].astype(np.int32))
+    errors: List[str] = []
+
+    def write_json():
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        for name, det in (("cells.json", 0), ("cell_detection.json", 1)):
+            rcode = lib.cv_write_cells_json(str(outdir / name).encode(), header, det, n, p(g["bbox"]), p(g["centroid"]), p(g["ct_off"]),
+                                            p(g["contour"]), p(prob), p(typ), p(rc), p(status), p(g["offset_global"]), p(g["edge"]),
+                                            p(g["edge_pos"]))
+            if rcode != _lib.CV_OK:
+                errors.append((lib.cv_last_error() or b"cv_write_cells_json failed").decode("utf-8", "replace"))
+    th = threading.Thread(target=write_json)
+    th.start()
+    if n:
+        D = allc.tokens.shape[1] if allc.tokens is not None else 0
+        x = allc.tokens.float().cpu() if allc.tokens is not None else torch.zeros((n, D))
+        lens = np.diff(g["ct_off"]).tolist()
+        graph = make_cell_graph(
+            x=x, positions=torch.from_numpy(g["centroid"].astype(np.float32)),
+            contours=list(torch.from_numpy(g["contour"].astype(np.float32)).split(lens)),     # views of ONE storage (`torch.Tensor(list)` per cell in the reference)
+            metadata={"wsi_metadata": wsi_metadata, "nuclei_types": nuclei_types})
+        torch.save(graph, outdir / "cells.pt")
     if geojson:
+        cells_all = allc.to_dicts(patch_size, downsampling, overlap)
         with open(outdir / "cells.geojson", "w") as f:
             json.dump(convert_geojson(cells_all, True), f, indent=2, default=_np_default)
         with open(outdir / "cell_detection.geojson", "w") as f:
             json.dump(convert_geojson(cells_all, False), f, indent=2, default=_np_default)
-    if len(cells_all):
-        D = allc.tokens.shape[1] if allc.tokens is not None else 0
-        x = allc.tokens.float().cpu() if allc.tokens is not None else torch.zeros((len(cells_all), D))
-        graph = make_cell_graph(
-            x=x, positions=torch.stack([torch.Tensor(c["centroid"]) for c in cells_all]),
-            contours=[torch.Tensor(c["contour"]) for c in cells_all],
-            metadata={"wsi_metadata": wsi_metadata, "nuclei_types": nuclei_types})
-        torch.save(graph, outdir / "cells.pt")
+    th.join()
+    if errors:
+        raise RuntimeError(errors[0])
 
 
 def _np_default(o):
@@ -432,131 +503,6 @@ def _np_default(o):
     if isinstance(o, np.ndarray):
         return o.tolist()
     raise TypeError(type(o))
-
-
-# ----------------------------------------------------------------------------------------------------
-# slide-level de-duplication (CellPostProcessor, cell_detection.py:600-767) — same rules, exact polygon geometry
-# ----------------------------------------------------------------------------------------------------
-def _poly_area(contour: np.ndarray) -> float:
-    """Area of the closed polygon through the contour points (shoelace), as `shapely.Polygon(contour).area`."""
-    pts = np.asarray(contour, dtype=np.float64)
-    if len(pts) < 3:
-        return 0.0
-    x, y = pts[:, 0], pts[:, 1]
-    return 0.5 * abs(float(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))))
-
-
-def _edge_crossings_y(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """y coordinates of all proper intersection points between the edges of polygons a and b."""
-    a0, a1 = a, np.roll(a, -1, axis=0)
-    b0, b1 = b, np.roll(b, -1, axis=0)
-    da, db = (a1 - a0)[:, None, :], (b1 - b0)[None, :, :]
-    w = (b0[None, :, :] - a0[:, None, :])
-    den = da[..., 0] * db[..., 1] - da[..., 1] * db[..., 0]
-    with np.errstate(divide="ignore", invalid="ignore"):
-        t = (w[..., 0] * db[..., 1] - w[..., 1] * db[..., 0]) / den
-        u = (w[..., 0] * da[..., 1] - w[..., 1] * da[..., 0]) / den
-        ok = (den != 0) & (t > 0) & (t < 1) & (u > 0) & (u < 1)
-        ys = a0[:, None, 1] + t * da[..., 1]
-    return ys[ok]
-
-
-def _x_intervals(poly: np.ndarray, yc: float) -> np.ndarray:
-    """Sorted x coordinates where the horizontal line y = yc crosses the polygon's edges (even-odd interior:
-    [x0, x1], [x2, x3], ...)."""
-    p0, p1 = poly, np.roll(poly, -1, axis=0)
-    y0, y1 = p0[:, 1], p1[:, 1]
-    hit = ((y0 <= yc) & (yc < y1)) | ((y1 <= yc) & (yc < y0))
-    xs = p0[hit, 0] + (yc - y0[hit]) * (p1[hit, 0] - p0[hit, 0]) / (y1[hit] - y0[hit])
-    return np.sort(xs)
-
-
-def _intersection_area(a: np.ndarray, b: np.ndarray) -> float:
-    """EXACT area of the intersection of two polygons (even-odd interiors) by slab decomposition: between two
-    consecutive event ordinates (vertices of either polygon, crossings of an a-edge with a b-edge) every interval end
-    point is linear in y, so the common length L(y) is linear and the midpoint rule integrates it exactly."""
-    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
-    if len(a) < 3 or len(b) < 3:
-        return 0.0
-    lo, hi = max(a[:, 1].min(), b[:, 1].min()), min(a[:, 1].max(), b[:, 1].max())
-    if hi <= lo or max(a[:, 0].min(), b[:, 0].min()) >= min(a[:, 0].max(), b[:, 0].max()):
-        return 0.0
-    ev = np.concatenate([a[:, 1], b[:, 1], _edge_crossings_y(a, b), [lo, hi]])
-    ev = np.unique(ev[(ev >= lo) & (ev <= hi)])
-    area = 0.0
-    for y0, y1 in zip(ev[:-1], ev[1:]):
-        ym = 0.5 * (y0 + y1)
-        xa, xb = _x_intervals(a, ym), _x_intervals(b, ym)
-        length = 0.0
-        for i in range(0, len(xa) - 1, 2):
-            for j in range(0, len(xb) - 1, 2):
-                length += max(0.0, min(xa[i + 1], xb[j + 1]) - max(xa[i], xb[j]))
-        area += length * (y1 - y0)
-    return area
-
-
-def _overlap_fractions(ca: dict, cb: dict) -> Tuple[float, float, float, float]:
-    """(intersection / area_a, intersection / area_b, area_a, area_b) of two cells' contour polygons — the quantities
-    the reference takes from shapely (`cell_detection.py:722-747`), computed exactly (no shapely here)."""
-    a, b = np.asarray(ca["contour"]), np.asarray(cb["contour"])
-    aa, ab = _poly_area(a), _poly_area(b)
-    inter = _intersection_area(a, b) if aa > 0 and ab > 0 else 0.0
-    return (inter / aa if aa else 0.0), (inter / ab if ab else 0.0), aa, ab
-
-
-def stitch_cells(cells: List[dict], logger: Optional[logging.Logger] = None) -> List[int]:
-    """Indices of the cells to keep: mid cells; margin cells; edge cells only if the neighbouring tile (first
-    `edge_patches` entry) produced no margin cells (:645-674); then up to 20 rounds of overlap removal where of every
-    group of cells overlapping by > 1 % of either area the largest *other* cell survives (:676-767)."""
-    idx_margin = [i for i, c in enumerate(cells) if c["cell_status"] != 0]
-    keep = [i for i, c in enumerate(cells) if c["cell_status"] == 0]
-    existing = {f"{cells[i]['patch_coordinates'][0]}_{cells[i]['patch_coordinates'][1]}" for i in idx_margin}
-    cleaned = []
-    for i in idx_margin:
-        c = cells[i]
-        if not c["edge_position"]:
-            cleaned.append(i)
-        else:
-            ep = c["edge_information"]["edge_patches"]
-            if ep is None or f"{ep[0][0]}_{ep[0][1]}" not in existing:
-                cleaned.append(i)
-    merged = sorted(cleaned)
-    for iteration in range(20):
-        grid: Dict[Tuple[int, int], List[int]] = defaultdict(list)
-        for i in merged:
-            (r0, c0), (r1, c1) = cells[i]["bbox"]
-            for gy in range(int(r0) // 64, int(r1) // 64 + 1):
-                for gx in range(int(c0) // 64, int(c1) // 64 + 1):
-                    grid[(gy, gx)].append(i)
-        done, out, overlaps = set(), [], 0
-        for i in merged:
-            if i in done:
-                continue
-            (r0, c0), (r1, c1) = cells[i]["bbox"]
-            cand = set()
-            for gy in range(int(r0) // 64, int(r1) // 64 + 1):
-                for gx in range(int(c0) // 64, int(c1) // 64 + 1):
-                    cand.update(grid[(gy, gx)])
-            sub = []
-            for j in sorted(cand):
-                if j == i or j in done:
-                    continue
-                (a0, b0), (a1, b1) = cells[j]["bbox"]
-                if a0 >= r1 or a1 <= r0 or b0 >= c1 or b1 <= c0:
-                    continue
-                fa, fb, _, area_j = _overlap_fractions(cells[i], cells[j])
-                if fa > 0.01 or fb > 0.01:
-                    overlaps += 1
-                    sub.append((area_j, j))
-                    done.add(j)
-            out.append(i if not sub else max(sub)[1])
-            done.add(i)
-        if logger:
-            logger.info(f"Iteration {iteration}: Found overlap of # cells: {overlaps}")
-        merged = sorted(set(out))
-        if overlaps == 0:
-            break
-    return sorted(keep + merged)
 
 
 def convert_geojson(cell_list: List[dict], polygons: bool = False) -> List[dict]:

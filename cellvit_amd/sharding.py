@@ -146,6 +146,16 @@ def all_gather_margin_records(ir: np.ndarray, fr: np.ndarray, ct: np.ndarray, de
     return cat(parts_i), cat(parts_f), cat(parts_c)
 
 
+def all_gather_int(v: int, device=None, group=None) -> List[int]:
+    """One integer from every rank (rank order); [v] without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [int(v)]
+    t = torch.tensor([int(v)], dtype=torch.int64, device=device or torch.device("cpu"))
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return [int(o.item()) for o in out]
+
+
 def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
     """all-gatherv of a [n, ...] tensor along dim 0 (rank order); identity without an initialised process group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

@@ -219,6 +219,33 @@ int cv_pp_run_params(cv_pp* pp, const uint8_t* bin_argmax, const uint8_t* type_a
  * reported), type_map u8 [B,H,W] (argmax of the one-hot type map; NULL with nr_types 0).  Outputs as cv_pp_run.       */
 int cv_pp_records(cv_pp* pp, int32_t* inst_map, const uint8_t* type_map, int B, int nr_types, cv_instance* recs,
                   int32_t* n_recs, int32_t* contours, int32_t* n_pts, void* stream);
+/* Slide-level de-duplication of margin cells — replaces the shapely STRtree queries + polygon intersections of
+ * CellPostProcessor._remove_overlap (cell_segmentation/inference/cell_detection.py:676-767) for the cells of one slide.
+ * All pointers are DEVICE pointers except n_pairs_host.  bbox i32 [n,4] = (rmin, cmin, rmax, cmax) in slide coordinates,
+ * ct_off i64 [n+1] = contour offsets (points) into ct_xy i32 [*,2] = (x, y) contour points in slide coordinates, extent =
+ * HOST i32 [4] (min row, min col, max row, max col over all boxes).  Outputs: pairs i32 [cap,2] = candidate pairs (i < j) whose
+ * boxes overlap strictly (order unspecified), inter f64 [cap] = EXACT area of the intersection of the two contour polygons
+ * (even-odd interiors; -1 where a fixed per-thread capacity was exceeded: evaluate that pair on the host), area f64 [n] = polygon
+ * areas.  Synchronises the stream (the pair count is returned to the host); CV_ERR_SHAPE when more than cap pairs exist.        */
+int cv_stitch_overlaps(const int32_t* bbox, const int64_t* ct_off, const int32_t* ct_xy, int n, const int32_t* extent,
+                       int32_t* pairs, double* inter, double* area, int cap, int32_t* n_pairs_host, void* stream);
+/* The greedy rounds of the same function (:706-767) over a pair list — HOST pointers, host code: per round cells are visited in
+ * index order, a visited cell collects its live, not yet visited overlap partners and the largest of them survives in its place
+ * (the cell itself when it has none); stops after a round without overlaps or max_rounds (reference: 20).  overlap[k] != 0 marks
+ * pairs overlapping by more than 1 % of either area; alive u8 [n] in/out; overlaps_out i32 [max_rounds] per-round counts.       */
+int cv_stitch_select(const int32_t* pairs, const uint8_t* overlap, int n_pairs, const double* area, uint8_t* alive, int n,
+                     int max_rounds, int32_t* rounds_out, int32_t* overlaps_out);
+/* Writer of `cells.json` / `cell_detection.json` (cell_detection.py:438-457) from packed HOST arrays — host code, no device.
+ * header = the rendered members '"wsi_metadata": ..., "processed_patches": ..., "type_map": ...' (without braces); per cell k:
+ * bbox i64 [n,4] and centroid f64 [n,2] in slide coordinates, contour points ct_xy i64 [*,2] with offsets ct_off i64 [n+1],
+ * type_prob, type, patch_rc i32 [n,2] = (row, col), status, offset_global i64 [n,2], edge u8 [n], edge_pos u8 [n,4] =
+ * [top, right, down, left] (get_cell_position, :787-817; edge_patches follow from get_edge_patch, :877-902).
+ * detection_only != 0 writes {bbox, centroid, type} per cell (the other arrays may be NULL).  Same JSON document as
+ * json.dump of the reference's dicts (keys, order, values; doubles with 17 significant digits), one cell per line.           */
+int cv_write_cells_json(const char* path, const char* header, int detection_only, int n, const int64_t* bbox,
+                        const double* centroid, const int64_t* ct_off, const int64_t* ct_xy, const double* type_prob,
+                        const int32_t* type, const int32_t* patch_rc, const int32_t* status, const int64_t* offset_global,
+                        const uint8_t* edge, const uint8_t* edge_pos);
 /* Cell-token pooling of the inference CLI (cell_detection.py:396-409) on the device record arrays of cv_pp_run:
  * out[rec_offset[b] + i, :] = mean over tokens_nhwc[b, floor(rmin/p):ceil(rmax/p), floor(cmin/p):ceil(cmax/p), :] for
  * record i < n_recs[b] (indices cast to uint8 as the reference does).  rec_offset: int64 [B] device (exclusive prefix

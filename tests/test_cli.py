@@ -8,6 +8,8 @@ import torch
 import yaml
 
 from cellvit_amd.inference import cell_detection as CD
+from cellvit_amd.inference import stitch as ST
+from oracle import stitch_ref as SR
 
 
 def test_parser_has_the_reference_flags():
@@ -46,26 +48,31 @@ def test_stitch_rules():
         _cell(300, 1004, 20, 0, 0, edge=True, pos=[0, 1, 0, 0]),   # edge cell whose neighbour tile exists -> dropped
         _cell(800, 2000, 20, 0, 1, edge=True, pos=[0, 1, 0, 0]),   # edge cell without neighbour tile (0,2) -> kept
     ]
-    keep = CD.stitch_cells(cells)
+    keep = SR.stitch_cells(cells)
     assert keep == [0, 2, 4]
 
 
-def test_polygon_geometry_exact():
+@pytest.mark.parametrize("G", [SR, ST])
+def test_polygon_geometry_exact(G):
+    """The oracle's polygon routines and the product's host copies (checker of the device kernel) on known answers."""
+    area = G._poly_area if G is SR else G.poly_area
+    inter = G._intersection_area if G is SR else G.intersection_area
     sq = np.array([[2, 2], [2, 8], [10, 8], [10, 2]])                       # 8 x 6 rectangle
-    assert CD._poly_area(sq) == 48.0
-    assert CD._intersection_area(sq, sq + np.array([4, 0])) == 4 * 6       # shifted by 4 in x
-    assert CD._intersection_area(sq, sq + np.array([20, 0])) == 0.0
+    assert area(sq) == 48.0
+    assert inter(sq, sq + np.array([4, 0])) == 4 * 6       # shifted by 4 in x
+    assert inter(sq, sq + np.array([20, 0])) == 0.0
     tri = np.array([[0, 0], [8, 0], [0, 8]])                               # right triangle, area 32
-    assert CD._poly_area(tri) == 32.0
+    assert area(tri) == 32.0
     box = np.array([[0, 0], [4, 0], [4, 4], [0, 4]])
-    assert abs(CD._intersection_area(tri, box) - 16.0) < 1e-12             # the box lies inside the triangle (x + y <= 8)
+    assert abs(inter(tri, box) - 16.0) < 1e-12             # the box lies inside the triangle (x + y <= 8)
     box2 = box + np.array([3, 3])                                          # [3,7]^2 cut by x + y = 8: corner triangle of legs 2
-    assert abs(CD._intersection_area(tri, box2) - 2.0) < 1e-12
+    assert abs(inter(tri, box2) - 2.0) < 1e-12
     ell = np.array([[0, 0], [6, 0], [6, 2], [2, 2], [2, 6], [0, 6]])       # concave L, area 20
-    assert CD._poly_area(ell) == 20.0
-    assert abs(CD._intersection_area(ell, np.array([[1, 1], [5, 1], [5, 5], [1, 5]])) - (4 + 3 + 0)) < 1e-12
-    fa, fb, aa, ab = CD._overlap_fractions({"contour": sq}, {"contour": sq + np.array([4, 0])})
-    assert (fa, fb, aa, ab) == (0.5, 0.5, 48.0, 48.0)
+    assert area(ell) == 20.0
+    assert abs(inter(ell, np.array([[1, 1], [5, 1], [5, 5], [1, 5]])) - (4 + 3 + 0)) < 1e-12
+    if G is SR:
+        fa, fb, aa, ab = SR._overlap_fractions({"contour": sq}, {"contour": sq + np.array([4, 0])})
+        assert (fa, fb, aa, ab) == (0.5, 0.5, 48.0, 48.0)
 
 
 def test_geojson_types_sorted_like_the_reference():
@@ -139,43 +146,148 @@ def _slide_cells_of(tiles, tile_ids, grid=3):
     return CD.SlideCells.concat(parts)
 
 
-def _stitch_worker(rank, world, port, q):
+def _to_dicts_scalar(sc, patch_size, downsampling, overlap):
+    """The per-cell formulation of `SlideCells.to_dicts` (cell_detection.py:341-391, one numpy expression per field)."""
+    from cellvit_amd import sharding as S
+    offs, lens = sc.contour_slices()
+    out = []
+    for k in range(len(sc.ir)):
+        i, f = sc.ir[k], sc.fr[k]
+        row, col = int(i[S.I_ROW]), int(i[S.I_COL])
+        off = np.array(S.global_offset(row, col, patch_size, downsampling, overlap))
+        bbox = np.array([[i[S.I_RMIN], i[S.I_CMIN]], [i[S.I_RMAX], i[S.I_CMAX]]])
+        d = {"bbox": (bbox + off).tolist(), "centroid": (f[[S.F_CX, S.F_CY]] + np.flip(off)).tolist(),
+             "contour": (sc.ct[offs[k]:offs[k] + lens[k]] + np.flip(off)).tolist(), "type_prob": float(f[S.F_PROB]),
+             "type": int(i[S.I_TYPE]), "patch_coordinates": [row, col], "cell_status": int(i[S.I_STATUS]),
+             "offset_global": off.tolist()}
+        if i[S.I_EDGE]:
+            pos = S.cell_edge_position(bbox, patch_size)
+            d["edge_position"] = True
+            d["edge_information"] = {"position": pos, "edge_patches": S.edge_patches(pos, row, col)}
+        else:
+            d["edge_position"] = False
+        out.append(d)
+    return out
+
+
+def test_to_dicts_vectorised_equals_per_cell_formulation():
+    tiles = _synthetic_slide_tiles()
+    sc = _slide_cells_of(tiles, list(range(9)))
+    for ds in (1, 2.0):
+        assert sc.to_dicts(1024, ds, 64) == _to_dicts_scalar(sc, 1024, ds, 64)
+
+
+def test_native_writers_produce_the_documents_of_json_dump(tmp_path):
+    """cells.json / cell_detection.json rendered by the library's host code from the arrays == json.dump of the per-cell
+    dicts (same keys in the same order, same values after parsing), cells.pt == the per-cell construction of the reference
+    (cell_detection.py:438-475); the geojson pair still goes through the dicts."""
+    tiles = _synthetic_slide_tiles(n_cells=400)
+    sc = _slide_cells_of(tiles, list(range(9)))
+    sc.fr[:, 2] = np.linspace(0.1, 1.0, len(sc))                 # type_prob values that need all 17 digits
+    sc.fr[:, 0] += 1.0 / 3.0
+    allc, dicts = CD.finalize_slide(sc, 1024, 2.0, 64)
+    meta = {"magnification": 40, "downsampling": 2.0, "label_map": {"background": 0}}
+    types = {"Background": 0, "Neoplastic": 1}
+    CD.write_outputs(tmp_path, meta, ["0_0", "0_1"], types, allc, True, 1024, 2.0, 64)
+    cells = json.load(open(tmp_path / "cells.json"))
+    want = json.loads(json.dumps({"wsi_metadata": meta, "processed_patches": ["0_0", "0_1"], "type_map": types, "cells": dicts}))
+    assert list(cells.keys()) == list(want.keys())
+    assert cells == want
+    assert [list(c.keys()) for c in cells["cells"][:50]] == [list(c.keys()) for c in want["cells"][:50]]
+    assert any(c["edge_position"] and c["edge_information"]["edge_patches"] for c in cells["cells"])
+    det = json.load(open(tmp_path / "cell_detection.json"))
+    assert det["cells"] == [{"bbox": c["bbox"], "centroid": c["centroid"], "type": c["type"]} for c in want["cells"]]
+    g = torch.load(tmp_path / "cells.pt", weights_only=False)
+    assert type(g).__name__ == "CellGraphDataWSI" and len(g.contours) == len(dicts)
+    assert torch.equal(g.positions, torch.stack([torch.Tensor(c["centroid"]) for c in dicts]))
+    assert all(torch.equal(a, torch.Tensor(c["contour"])) for a, c in zip(g.contours, dicts))
+    assert torch.equal(g.x, allc.tokens)
+    gj = json.load(open(tmp_path / "cells.geojson"))
+    assert sum(len(f["geometry"]["coordinates"]) for f in gj) == len(dicts)
+    # an empty slide still writes valid documents
+    empty = CD.SlideCells()
+    CD.write_outputs(tmp_path, meta, [], types, empty, False, 1024, 2.0, 64)
+    assert json.load(open(tmp_path / "cells.json"))["cells"] == []
+
+
+def test_array_stitch_equals_the_dict_oracle_on_the_synthetic_slide():
+    """`stitch.stitch_margin_records` (packed arrays; host route of the geometry here, the HIP kernels in
+    tests/test_gpu_stitch.py) keeps exactly the cells the dict-based restatement of CellPostProcessor keeps."""
+    from cellvit_amd import sharding as S
+    for seed, n_cells in ((0, 700), (5, 1500)):
+        tiles = _synthetic_slide_tiles(seed=seed, n_cells=n_cells)
+        sc = _slide_cells_of(tiles, list(range(9)))
+        dicts = _to_dicts_scalar(sc, 1024, 1, 64)
+        keep_ref = SR.stitch_cells(dicts)
+        is_margin = sc.ir[:, S.I_STATUS] != 0
+        m_idx = np.nonzero(is_margin)[0]
+        margin = sc.select(m_idx)
+        keep_m = ST.stitch_margin_records(margin.ir, margin.ct, 1024, 1, 64)
+        keep = sorted(np.nonzero(~is_margin)[0].tolist() + m_idx[keep_m].tolist())
+        assert keep == keep_ref
+        assert 0 < len(keep_m) < len(m_idx)
+        # the pair list and the edge rule on their own
+        bbox, off, ctg = ST.global_geometry(margin.ir, margin.ct, 1024, 1, 64)
+        pairs = ST.candidate_pairs_host(bbox)
+        b = bbox.astype(np.int64)
+        brute = [(i, j) for i in range(len(b)) for j in range(i + 1, len(b))
+                 if not (b[j, 0] >= b[i, 2] or b[j, 2] <= b[i, 0] or b[j, 1] >= b[i, 3] or b[j, 3] <= b[i, 1])] if len(b) <= 1200 else None
+        if brute is not None:
+            assert [tuple(p) for p in pairs.tolist()] == brute
+
+
+def _stitch_worker(rank, world, port, q, grid=3, block=2):
     import torch.distributed as dist
     from cellvit_amd import sharding as S
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    tiles = _synthetic_slide_tiles()
-    local = _slide_cells_of(tiles, S.shard_tiles(9, rank, world, block=2))
+    tiles = _synthetic_slide_tiles(grid=grid)
+    local = _slide_cells_of(tiles, S.shard_tiles(grid * grid, rank, world, block=block), grid=grid)
     allc, dicts = CD.finalize_slide(local, 1024, 1, 64)
     q.put((rank, dicts, allc.tokens.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world2_stitch_equals_world1():
-    """Sharding the slide over 2 ranks (block-cyclic, gloo) must give exactly the single-process cell set, in the same
-    order, with the same token rows: only margin records are exchanged and ONE global stitch runs."""
+def _run_world2(grid, block):
     import socket
     import torch.multiprocessing as mp
-    tiles = _synthetic_slide_tiles()
-    ref_all, ref_dicts = CD.finalize_slide(_slide_cells_of(tiles, list(range(9))), 1024, 1, 64)
-    n_before = sum(len(d) for d in tiles.values())
-    assert 0 < len(ref_dicts) < n_before                     # duplicates in the overlap margins were removed
-    assert any(c["cell_status"] != 0 for c in ref_dicts) and any(c["edge_position"] for c in ref_dicts)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_stitch_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_stitch_worker, args=(r, 2, port, q, grid, block)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for _, dicts, tok in res:
+    return res
+
+
+def test_world2_stitch_equals_world1():
+    """Sharding the slide over 2 ranks (block-cyclic, gloo) must give exactly the single-process cell set, in the same
+    order, with the same token rows: only margin records are exchanged and ONE global stitch runs."""
+    tiles = _synthetic_slide_tiles()
+    ref_all, ref_dicts = CD.finalize_slide(_slide_cells_of(tiles, list(range(9))), 1024, 1, 64)
+    n_before = sum(len(d) for d in tiles.values())
+    assert 0 < len(ref_dicts) < n_before                     # duplicates in the overlap margins were removed
+    assert any(c["cell_status"] != 0 for c in ref_dicts) and any(c["edge_position"] for c in ref_dicts)
+    for _, dicts, tok in _run_world2(3, 2):
+        assert dicts == ref_dicts
+        assert np.array_equal(tok, ref_all.tokens.numpy())
+
+
+def test_world2_with_a_rank_that_received_no_tile():
+    """4 tiles in blocks of 8 over 2 ranks: rank 1 gets nothing (n_tiles <= rank * batch).  Every collective of
+    finalize_slide is still entered by both ranks (token gather with an agreed width and a [0, D] contribution)."""
+    tiles = _synthetic_slide_tiles(grid=2)
+    ref_all, ref_dicts = CD.finalize_slide(_slide_cells_of(tiles, list(range(4)), grid=2), 1024, 1, 64)
+    assert len(ref_dicts) > 0
+    for _, dicts, tok in _run_world2(2, 8):
         assert dicts == ref_dicts
         assert np.array_equal(tok, ref_all.tokens.numpy())
 
@@ -346,6 +458,7 @@ def test_cli_route_with_real_cells_against_the_oracle(tmp_path):
     assert k == len(local)
     # ---- whole CLI call: files == one global stitch of those cells
     res = inf.process_wsi(wsi, batch_size=3, geojson=True)
+    assert res["margin_records"] > 0 and res["margin_kept"] < res["margin_records"]
     out = slide / "cell_detection"
     cells = json.load(open(out / "cells.json"))
     _, want_dicts = CD.finalize_slide(local, 1024, 1, 64)

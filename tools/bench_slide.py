@@ -1,0 +1,166 @@
+"""Slide-level benchmark (BASELINE.json configs[3]): a synthetic pre-patched slide of N 1024^2 tiles with 64-px overlap
+through the whole CLI route — PNG decode -> forward (CellViT-SAM-H fp16, seeded random weights, really executed) ->
+on-device post-processing -> token pooling -> records -> margin-record exchange -> slide-level de-duplication -> writers.
+
+Random-weight logits contain no nuclei, so after every forward the argmax planes / HV map handed to the post-processing are
+REPLACED by the tile's crop of a periodic synthetic nucleus world (cellvit_amd.synth.synth_world_maps, ~800 nuclei per tile):
+neighbouring tiles then see the same nuclei in their overlap, which is what the stitch needs as input.  The forward's cost is
+in the tile loop's time; its outputs are not used.
+
+    python tools/bench_slide.py [--tiles 1024] [--batch 16] [--model samh|vit256] [--ranks 1|2]
+`--ranks 2` runs two processes on the ONE GPU of the box (backend gloo for the exchange): it exercises the sharded route
+(margin-record all-gatherv, replicated stitch, writer's gather), not a scaling claim.
+Prints one JSON line: tile-loop tiles/s, seconds of exchange / stitch / to_dicts / writers, cell counts.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class WorldMapsModel:
+    """The real model, whose planes / HV outputs are replaced by world crops selected by pixel (0, 0, 0) of each tile."""
+
+    def __init__(self, real, world, device):
+        import numpy as np
+        import torch
+        from cellvit_amd.synth import world_tile
+        self.real = real
+        self.patch_size, self.num_nuclei_classes, self.embed_dim = real.patch_size, real.num_nuclei_classes, real.embed_dim
+        crops = [world_tile(world, r, c) for r in range(2) for c in range(2)]           # period 2 tiles in each direction
+        self.typ = torch.from_numpy(np.stack([c[0] for c in crops])).to(device)
+        self.bin = torch.from_numpy(np.stack([c[1] for c in crops])).to(device)
+        self.hv = torch.from_numpy(np.stack([c[2] for c in crops])).to(device)
+        self._last_argmax = None
+
+    def forward_u8(self, x_u8, mean, std, retrieve_tokens=False):
+        out = self.real.forward_u8(x_u8, mean, std, retrieve_tokens=retrieve_tokens)
+        cls = x_u8[:, 0, 0, 0].long()
+        self._last_argmax = (self.bin[cls], self.typ[cls])
+        out["hv_map"] = self.hv[cls]
+        return out
+
+
+NUCLEI_TYPES = {"Background": 0, "Neoplastic": 1, "Inflammatory": 2, "Connective": 3, "Dead": 4, "Epithelial": 5}
+
+
+def build_slide(tmp, tiles, model, with_ckpt=True):
+    import numpy as np
+    import torch
+    import yaml
+    from PIL import Image
+    from cellvit_amd.spec import cellvit256_config, cellvit_sam_config
+    from cellvit_amd.weights import make_state_dict, synthetic_tile_u8
+    if with_ckpt:
+        cfg = cellvit_sam_config("SAM-H") if model == "samh" else cellvit256_config()
+        ckpt = {"arch": "CellViTSAM" if model == "samh" else "CellViT256", "model_state_dict": make_state_dict(cfg, 0),
+                "config": {"data.num_nuclei_classes": 6, "data.num_tissue_classes": 19, "model.backbone": "SAM-H" if model == "samh" else "default",
+                           "training.mixed_precision": True, "dataset_config.nuclei_types": NUCLEI_TYPES}}
+        torch.save(ckpt, os.path.join(tmp, "ckpt.pth"))
+    slide = os.path.join(tmp, "slide")
+    os.makedirs(os.path.join(slide, "patches"))
+    for k in range(4):                                   # one source image per (row % 2, col % 2) class; pixel (0,0,0) names the class
+        img = synthetic_tile_u8(k, 1024, he_like=True).copy()
+        img[0, 0, 0] = k
+        Image.fromarray(img).save(os.path.join(slide, "patches", f"src{k}.png"))
+    side = int(np.ceil(np.sqrt(tiles)))
+    meta = []
+    for t in range(tiles):
+        row, col = divmod(t, side)
+        name = f"slide_{row}_{col}.png"
+        os.symlink(f"src{(row % 2) * 2 + (col % 2)}.png", os.path.join(slide, "patches", name))
+        meta.append({name: {"row": row, "col": col}})
+    with open(os.path.join(slide, "patch_metadata.json"), "w") as f:
+        json.dump(meta, f)
+    with open(os.path.join(slide, "metadata.yaml"), "w") as f:
+        yaml.safe_dump({"magnification": 40, "downsampling": 1, "patch_size": 1024, "patch_overlap": 64,
+                        "label_map": {"background": 0}, "base_magnification": 40}, f)
+    return os.path.join(tmp, "ckpt.pth"), slide
+
+
+def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batches=2, world_seed=3, real_model=None):
+    """One slide through process_wsi on this process's rank; returns the stats dict of rank 0 (None on other ranks).
+    `real_model`: an already built cellvit_amd model (bench.py's); otherwise a seeded checkpoint is written and loaded
+    through the CLI's own checkpoint path."""
+    import torch
+    import torch.distributed as dist
+    from cellvit_amd.inference import cell_detection as CD
+    from cellvit_amd.synth import synth_world_maps
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world_n = dist.get_world_size() if dist.is_initialized() else 1
+    own_tmp = tmp is None
+    if own_tmp:
+        tmp = tempfile.mkdtemp(prefix="cva_slide_")
+    if rank == 0:
+        build_slide(tmp, tiles, model, with_ckpt=real_model is None)
+    if world_n > 1:
+        dist.barrier()
+    ckpt, slide = os.path.join(tmp, "ckpt.pth"), os.path.join(tmp, "slide")
+    if real_model is None:
+        inf = CD.CellSegmentationInference(ckpt, torch.cuda.current_device())
+    else:                                                # the CLI object around a model that already lives on the device
+        import logging
+        inf = CD.CellSegmentationInference.__new__(CD.CellSegmentationInference)
+        inf.logger = logging.getLogger("cellvit_amd")
+        inf.device = torch.device("cuda", torch.cuda.current_device())
+        inf.run_conf = {"dataset_config": {"nuclei_types": NUCLEI_TYPES}}
+        inf.mixed_precision, inf.model, inf.mean, inf.std, inf.pool_cap = True, real_model, (0.5,) * 3, (0.5,) * 3, 2048
+    inf.model = WorldMapsModel(inf.model, synth_world_maps(world_seed, 1920, 2800), inf.device)
+    wsi = CD.PatchedSlide("slide", slide)
+    inf.run_tiles(wsi, list(range(min(tiles, warmup_batches * batch))), batch)               # warm-up (engine, workspaces)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = inf.process_wsi(wsi, batch_size=batch, geojson=geojson)
+    total = time.perf_counter() - t0
+    out_bytes = sum(os.path.getsize(os.path.join(stats["outdir"], f)) for f in os.listdir(stats["outdir"])) if rank == 0 else 0
+    if rank != 0:
+        return None
+    return {"tool": "bench_slide", "model": model, "tiles": tiles, "batch": batch, "ranks": world_n,
+            "tile_loop_tiles_per_s_rank0": stats["tiles"] / stats["t_loop"], "tile_loop_s": stats["t_loop"],
+            "cells_before_cleaning_rank0": stats["cells_before_cleaning"], "cells_written": stats["n_cells"],
+            "margin_records": stats["margin_records"], "margin_kept": stats["margin_kept"],
+            "exchange_s": stats["exchange_s"], "stitch_s": stats["stitch_s"], "to_dicts_s": stats["to_dicts_s"],
+            "write_s": stats["write_s"], "slide_total_s": total, "slide_tiles_per_s": tiles / total,
+            "output_MB": out_bytes / 1e6, "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--model", default="samh", choices=["samh", "vit256"])
+    ap.add_argument("--ranks", type=int, default=1)
+    ap.add_argument("--geojson", action="store_true")
+    ap.add_argument("--tmp", default=None)
+    args = ap.parse_args()
+    if args.ranks > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        tmp = tempfile.mkdtemp(prefix="cva_slide_")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + ["--tmp", tmp]
+        sys.exit(subprocess.call(cmd))
+    import torch
+    import torch.distributed as dist
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")                   # all ranks share the box's one GPU: host-side exchange
+    torch.cuda.set_device(0)
+    rec = run(args.tiles, args.batch, args.model, args.geojson, args.tmp)
+    if rec is not None:
+        print(json.dumps(rec))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

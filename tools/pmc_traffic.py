@@ -60,7 +60,13 @@ def main():
                 out[BENCH_KEYS[key]] = f2 + w
     out["_detail_MiB_per_launch"] = detail
     path = os.path.join(ROOT, "profiles", sys.argv[3] if len(sys.argv) > 3 else "traffic_latest.json")
-    out["_tiles_per_step"] = "bench.py default (--batch)"
+    # provenance (bench.py prints it next to roofline.traffic): tiles per step of the profiled command, commit of the tree
+    import subprocess
+    out["tiles_per_step"] = int(os.environ.get("PMC_TILES_PER_STEP", "64"))       # bench.py default --batch unless the caller says otherwise
+    try:
+        out["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        out["commit"] = None
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(detail, indent=1))
 
