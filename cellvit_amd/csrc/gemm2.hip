@@ -1,4 +1,6 @@
-// 256 x 128 x 32 fp16 MFMA contraction, TWO independent workgroups per CU (gfx950).
+// 256 x 128 x 32 fp16 MFMA contraction, TWO independent workgroups per CU (gfx950) — an EXPERIMENT, compiled into the ablation
+// flavour only (python -m cellvit_amd.build --ablation; CVA_GEMM2 = 1).  Measured 15-25 % slower than gemm8.hip in all three
+// variants that were tried (profiles/r03_exp_gemm2.txt); results are correct (full-matrix checks, no races).
 //
 // Why: the additive ablations of the 256 x 256 kernels (gemm8.hip: 8 waves in barrier-separated phases; gemm4.hip: one wave per
 // SIMD) say that the matrix pipe idles while a workgroup does anything else — operand DMA issue (the waves queue for the CU's
@@ -11,10 +13,10 @@
 // Workgroup: 256 threads = 4 waves, 2 (M) x 2 (N); tile 256 x 128, wave tile 128 x 64 = 8 x 4 fragments of
 // v_mfma_f32_16x16x32_f16 (128 accumulator VGPRs, as gemm8.hip) — so the direct epilogues of gemm8_epi.h apply unchanged.
 // K is walked in steps of 32 (= one MFMA K) through a ring of THREE 24-KiB stages (A: 16 fragment blocks of 1 KiB, W: 8): 72 KiB
-// per workgroup + bias + the GELU table = 77 KiB, two workgroups fit the CU's 160 KiB.  A fragment block is 16 rows x 64 B stored
-// in the order the MFMA lanes read it (lane g*16 + li <- row li, 16-byte piece g): it is written by ONE LDS-DMA instruction whose
-// lane l fetches (row l & 15, piece l >> 4), and read by ds_read_b128 at block + lane * 16 — lane-linear, bank-conflict free
-// without a swizzle.  A wave issues 6 of the 24 blocks of a stage.
+// per workgroup + bias + the GELU table = 78 KiB, two workgroups fit the CU's 160 KiB.  A fragment block is 16 rows x 64 B, written
+// by ONE LDS-DMA instruction (lane l: row l >> 2, slot l & 3) with a source-side XOR swizzle of the four 16-byte slots of a row
+// that makes the fragment reads (ds_read_b128: lane (g, li) <- row li, piece g) bank-conflict free.  A wave issues 6 of the 24
+// blocks of a stage.
 //
 // (GELU: the x * Phi(x) table of gemm8_epi.h at half the resolution, h = 1/64: |dPhi| < 7.6e-6, still two orders below half an
 // fp16 ulp of the result — the table has to fit twice into a CU.)
@@ -61,7 +63,12 @@ __global__ __launch_bounds__(G2_NT, 2) void gemm2_kernel(const GemmParams p) {
 
     // ---- DMA state of the tile whose K steps are staged NEXT.  Block b of a stage: b < 16 -> A rows 16b .. 16b+15, else W rows
     // 16(b-16) ..; this wave issues blocks wave + 4q, q = 0 .. 5 (q < 4: A, q >= 4: W).  Lane l fetches (row l & 15, piece l >> 4).
-    const int drow = lane & 15, dpc = lane >> 4;
+    // DMA lane l -> row l >> 2, 16-byte LDS slot l & 3 of the row's 64 B: four ADJACENT lanes fetch one row segment (coalesced; with
+    // the lane-linear order of the first version — lane -> (row l & 15, piece l >> 4) — every 16-lane quantum of an instruction touched
+    // 16 different lines: measured 35 % slower than gemm8.hip).  LDS slot pp of row r holds logical piece pp ^ SWZ[(r >> 2) & 3]:
+    // with SWZ = {0, 2, 3, 1} the 16 lanes of every ds_read_b128 service group hit 16 different bank quads.
+    const int swz_tab = 0x1320;                     // SWZ[k] = (swz_tab >> 4k) & 3
+    const int drow = lane >> 2, dpc = (lane & 3) ^ ((swz_tab >> (((drow >> 2) & 3) * 4)) & 3);
     unsigned voff[6];
     const unsigned char* Ab;
     const unsigned char* Wb;
@@ -113,8 +120,9 @@ __global__ __launch_bounds__(G2_NT, 2) void gemm2_kernel(const GemmParams p) {
         }
     };
 
-    // fragment read addresses: block base + lane * 16 (lane-linear); A blocks wr*8 + i, W blocks 16 + wc*4 + j
-    const unsigned rd0 = lds0 + lane * 16;
+    // fragment read addresses: lane (g, li) reads logical piece g of row li = LDS slot g ^ SWZ[(li >> 2) & 3]; A blocks wr*8 + i, W blocks 16 + wc*4 + j
+    const int fg = lane >> 4, fli = lane & 15;
+    const unsigned rd0 = lds0 + fli * 64 + ((fg ^ ((swz_tab >> (((fli >> 2) & 3) * 4)) & 3)) << 4);
     const unsigned a_rd = rd0 + (wr * 8) * G2_BLK, w_rd = rd0 + (16 + wc * 4) * G2_BLK;      // + slot * G2_STAGE + i * 1 KiB
 
     if (OMODE == OUT_LINEAR && p.act == ACT_GELU) {               // (read only in epilogues: many barriers later)
@@ -138,6 +146,10 @@ __global__ __launch_bounds__(G2_NT, 2) void gemm2_kernel(const GemmParams p) {
                    "+v"(FW[SET][2]), "+v"(FW[SET][3])                                                                  \
                  :: "memory")
 #define G2_MM(SET, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FW[SET][j], FA[SET][i], acc[i][j], 0, 0, 0)
+// DMA block q of the step being staged (issued between the MFMA rows: one load per row instead of a burst of six per wave —
+// 24 per workgroup — behind the barrier, where they queue for the CU's address unit)
+#define G2_DMA(q, base)                                                                                                \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[q]), "s"(base), "s"(d0_ + (q) * 4 * G2_BLK) : "memory")
 // one row of a step: A fragment i x the 4 W fragments, then one slot (fragment reads of the next step)
 #define G2_ROW(SET, i, OP)                                                                                             \
     do { G2_MM(SET, i, 0); G2_MM(SET, i, 1); G2_MM(SET, i, 2); G2_MM(SET, i, 3); OP; G2_SB(); } while (0)
@@ -147,17 +159,21 @@ __global__ __launch_bounds__(G2_NT, 2) void gemm2_kernel(const GemmParams p) {
     do {                                                                                                               \
         G2_VMCNT(6); G2_SB();                                                                                          \
         __builtin_amdgcn_s_barrier(); G2_SB();                                                                         \
-        dma_advance(s_cur);                                                                                            \
+        const int kd_ = dtile < ntiles ? dkt : 0;   /* (past the last tile: step 0 of the last tile again: 6 loads per step) */ \
+        const unsigned char* ab_ = uniform_ptr(Ab + (long)kd_ * (G2_BK * 2));                                          \
+        const unsigned char* wb_ = uniform_ptr(Wb + (long)kd_ * (G2_BK * 2));                                          \
+        const unsigned d0_ = __builtin_amdgcn_readfirstlane(lds_wave + s_cur);                                         \
         const unsigned a_nx = a_rd + s_nxt, w_nx = w_rd + s_nxt;                                                       \
         G2_WAIT_SET(SET); G2_SB();                                                                                     \
-        G2_ROW(SET, 0, G2_RD_W(SET ^ 1, 0); G2_RD_W(SET ^ 1, 1));                                                       \
-        G2_ROW(SET, 1, G2_RD_W(SET ^ 1, 2); G2_RD_W(SET ^ 1, 3));                                                       \
-        G2_ROW(SET, 2, G2_RD_A(SET ^ 1, 0); G2_RD_A(SET ^ 1, 1));                                                       \
-        G2_ROW(SET, 3, G2_RD_A(SET ^ 1, 2); G2_RD_A(SET ^ 1, 3));                                                       \
-        G2_ROW(SET, 4, G2_RD_A(SET ^ 1, 4); G2_RD_A(SET ^ 1, 5));                                                       \
-        G2_ROW(SET, 5, G2_RD_A(SET ^ 1, 6); G2_RD_A(SET ^ 1, 7));                                                       \
+        G2_ROW(SET, 0, G2_RD_W(SET ^ 1, 0); G2_RD_W(SET ^ 1, 1); G2_DMA(0, ab_));                                       \
+        G2_ROW(SET, 1, G2_RD_W(SET ^ 1, 2); G2_RD_W(SET ^ 1, 3); G2_DMA(1, ab_));                                       \
+        G2_ROW(SET, 2, G2_RD_A(SET ^ 1, 0); G2_RD_A(SET ^ 1, 1); G2_DMA(2, ab_));                                       \
+        G2_ROW(SET, 3, G2_RD_A(SET ^ 1, 2); G2_RD_A(SET ^ 1, 3); G2_DMA(3, ab_));                                       \
+        G2_ROW(SET, 4, G2_RD_A(SET ^ 1, 4); G2_RD_A(SET ^ 1, 5); G2_DMA(4, wb_));                                       \
+        G2_ROW(SET, 5, G2_RD_A(SET ^ 1, 6); G2_RD_A(SET ^ 1, 7); G2_DMA(5, wb_));                                       \
         G2_ROW(SET, 6, (void)0);                                                                                       \
         G2_ROW(SET, 7, (void)0);                                                                                       \
+        dma_cursor_move();                                                                                             \
         { const unsigned t_ = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t_; }                                         \
     } while (0)
 
@@ -170,13 +186,16 @@ __global__ __launch_bounds__(G2_NT, 2) void gemm2_kernel(const GemmParams p) {
     int bslot = 0;                                  // bias slot of the tile the DMA cursor is in
     tile_setup(dtile, dm0, dn0);
     stage_bias(dn0, bslot);
-    auto dma_advance = [&](unsigned soff) {         // stage the cursor's K step into the slot at `soff`, move the cursor
-        stage(soff, dtile < ntiles ? dkt : 0);      // (past the last tile: step 0 of the last tile again — every step issues 6 loads)
+    auto dma_cursor_move = [&]() {                  // after a step's 6 loads have been issued
         if (++dkt == nk) {
             dkt = 0;
             if (dtile < ntiles) dtile += gridDim.x;
             if (dtile < ntiles) { bslot ^= 1; tile_setup(dtile, dm0, dn0); stage_bias(dn0, bslot); }
         }
+    };
+    auto dma_advance = [&](unsigned soff) {         // stage the cursor's K step into the slot at `soff`, move the cursor (prologue)
+        stage(soff, dtile < ntiles ? dkt : 0);      // (past the last tile: step 0 of the last tile again — every step issues 6 loads)
+        dma_cursor_move();
     };
     int m0 = dm0, n0 = dn0;                         // the tile being ACCUMULATED
     unsigned s_cur = 0, s_nxt = G2_STAGE, s_nn = 2 * G2_STAGE;
@@ -243,6 +262,10 @@ int launch2(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+#ifndef CVA_ABLATION
+bool gemm2_supported(const GemmParams&) { return false; }
+int launch_gemm2(const GemmParams&, hipStream_t) { return -1; }
+#else
 bool gemm2_supported(const GemmParams& p) {
     if (p.out_mode != OUT_LINEAR) return false;
     if (p.M % G2_BM || p.N % G2_BN || p.K % (2 * G2_BK) || p.K < 4 * G2_BK) return false;
@@ -252,5 +275,6 @@ bool gemm2_supported(const GemmParams& p) {
 }
 
 int launch_gemm2(const GemmParams& p, hipStream_t stream) { return launch2<OUT_LINEAR>(p, stream); }
+#endif
 
 }  // namespace cva
