@@ -48,12 +48,14 @@ def tile_offsets(row: np.ndarray, col: np.ndarray, patch_size: int, downsampling
     return xg, yg
 
 
-def global_geometry(ir: np.ndarray, ct: np.ndarray, patch_size: int, downsampling: float, overlap: int):
+def global_geometry(ir: np.ndarray, ct: np.ndarray, patch_size: int, downsampling: float, overlap: int, offsets=None):
     """Slide-coordinate boxes and contours of packed records, exactly as `SlideCells.to_dicts` shifts them
     (cell_detection.py:351-359: rows += x_global, cols += y_global; contour (x, y) += (y_global, x_global)).
+    `offsets` = (x_global, y_global) per record where the caller's tiling is not the WSI one (MoNuSeg: i * 256 - i * overlap).
     Returns (bbox int32 [n,4] = rmin, cmin, rmax, cmax; contour offsets int64 [n+1]; contour points int32 [m,2])."""
     n = len(ir)
-    xg, yg = tile_offsets(ir[:, S.I_ROW], ir[:, S.I_COL], patch_size, downsampling, overlap)
+    xg, yg = offsets if offsets is not None else tile_offsets(ir[:, S.I_ROW], ir[:, S.I_COL], patch_size, downsampling, overlap)
+    xg, yg = np.asarray(xg, np.int64), np.asarray(yg, np.int64)
     bbox = ir[:, S.I_RMIN:S.I_CMAX + 1].astype(np.int64) + np.stack([xg, yg, xg, yg], 1)
     lens = ir[:, S.I_CLEN].astype(np.int64)
     off = np.zeros(n + 1, np.int64)
@@ -237,13 +239,13 @@ def select_rounds(pairs: np.ndarray, inter: np.ndarray, area: np.ndarray, alive:
 
 
 def stitch_margin_records(ir: np.ndarray, ct: np.ndarray, patch_size: int, downsampling: float, overlap: int,
-                          device: Optional[torch.device] = None, logger: Optional[logging.Logger] = None) -> np.ndarray:
+                          device: Optional[torch.device] = None, logger: Optional[logging.Logger] = None, offsets=None) -> np.ndarray:
     """Indices (ascending) of the MARGIN records (`ir` holds only cells with status != 0, in slide order) that survive
     `CellPostProcessor.post_process_cells`."""
     n = len(ir)
     if n == 0:
         return np.zeros(0, np.int64)
-    bbox, off, ctg = global_geometry(ir, ct, patch_size, downsampling, overlap)
+    bbox, off, ctg = global_geometry(ir, ct, patch_size, downsampling, overlap, offsets)
     alive = edge_rule(ir, patch_size)
     if device is not None and device.type == "cuda":
         pairs, inter, area = overlaps_device(bbox, off, ctg, device)

@@ -61,7 +61,8 @@ def synth_nuclei_maps(tile_idx: int, size: int = 1024, n_cells: int = 800, n_typ
     return tmap, fg.astype(np.uint8), hv.astype(np.float32), inst
 
 
-def synth_world_maps(seed: int, size: int = 1920, n_cells: int = 2800, n_types: int = 6, noise: float = 0.03):
+def synth_world_maps(seed: int, size: int = 1920, n_cells: int = 2800, n_types: int = 6, noise: float = 0.03,
+                     return_inst: bool = False):
     """A PERIODIC nucleus world (torus of `size` pixels): (type_map u8, binary_map u8, hv float32 [2,H,W]) whose crops at
     any offset (numpy `take(..., mode='wrap')`) are mutually consistent — neighbouring slide tiles cut from it see the SAME
     nuclei in their 64-px overlap, which is what the slide-level de-duplication needs as input.  Same
@@ -120,13 +121,15 @@ def synth_world_maps(seed: int, size: int = 1920, n_cells: int = 2800, n_types: 
     flip = rng.random((H, W)) < 0.10
     tnoise = rng.integers(0, n_types, size=(H, W)).astype(np.uint8)
     tmap = np.where(flip & fg, tnoise, tmap).astype(np.uint8)
+    if return_inst:
+        return tmap, fg.astype(np.uint8), hv, inst
     return tmap, fg.astype(np.uint8), hv
 
 
 def world_tile(world, row: int, col: int, patch_size: int = 1024, overlap: int = 64):
     """The (type_map, binary_map, hv) crop a slide tile (row, col) sees: origin = the reference's global tile offset at
     downsampling 1 (cell_detection.py:341-350: row * patch - (row + 0.5) * overlap), wrapped on the torus."""
-    tm, bm, hv = world
+    tm, bm, hv = world[:3]
     H, W = tm.shape
     y0 = int(row * patch_size - (row + 0.5) * overlap)
     x0 = int(col * patch_size - (col + 0.5) * overlap)

@@ -456,6 +456,11 @@ def test_cli_route_with_real_cells_against_the_oracle(tmp_path):
             k += 1; n_t += 1
         assert n_t > 300
     assert k == len(local)
+    # ---- tiles with more records than fixed pooling slots take the exact-size pooling pass: same cells, same token rows
+    inf.pool_cap = 64
+    local2, _, _ = inf.run_tiles(wsi, [0, 1, 2, 3], batch_size=3)
+    inf.pool_cap = 2048
+    assert np.array_equal(local2.ir, local.ir) and torch.equal(local2.tokens.cpu(), local.tokens.cpu())
     # ---- whole CLI call: files == one global stitch of those cells
     res = inf.process_wsi(wsi, batch_size=3, geojson=True)
     assert res["margin_records"] > 0 and res["margin_kept"] < res["margin_records"]

@@ -1,26 +1,30 @@
 #!/bin/bash
 # One GPU-box call that produces the round's evidence under gpurun_out/$1 (copy what should be judged into profiles/).
-#   tools/gpu_evidence.sh r02f [tests]
+#   tools/gpu_evidence.sh r03f [tests]
 OUT=gpurun_out/${1:-evidence}
 mkdir -p $OUT
 export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 if [ "$2" == "tests" ]; then
   python -m pytest tests -m gpu -q -s > $OUT/pytest.log 2>&1; echo "pytest rc=$?" > $OUT/rc.txt; tail -4 $OUT/pytest.log
 fi
-python bench.py > $OUT/bench_f16.json 2> $OUT/bench_f16.err; echo "bench f16 rc=$?" >> $OUT/rc.txt
-python bench.py --dtype f8 > $OUT/bench_f8.json 2> $OUT/bench_f8.err; echo "bench f8 rc=$?" >> $OUT/rc.txt
+( time python bench.py ) > $OUT/bench_f16.json 2> $OUT/bench_f16.err; echo "bench f16 rc=$?" >> $OUT/rc.txt; grep real $OUT/bench_f16.err >> $OUT/rc.txt
+python bench.py --dtype f8 --no-extras > $OUT/bench_f8.json 2> $OUT/bench_f8.err; echo "bench f8 rc=$?" >> $OUT/rc.txt
 python bench.py --model vit256 --no-cpu-baseline > $OUT/bench_vit256.json 2> $OUT/bench_vit256.err; echo "bench vit256 rc=$?" >> $OUT/rc.txt
+python bench.py --batch 128 --steps 3 --no-cpu-baseline --no-extras > $OUT/bench_f16_b128.json 2> $OUT/bench_f16_b128.err; echo "bench b128 rc=$?" >> $OUT/rc.txt
 ROOT=$(pwd)
+export PMC_TILES_PER_STEP=64
 for dt in f16 f8; do
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_$dt -o prof -- python $ROOT/bench.py --dtype $dt --no-cpu-baseline > $ROOT/$OUT/bench_${dt}_under_rocprof.json 2> $ROOT/$OUT/rocprof_$dt.err)
-  (cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_f_$dt -o pmc -- python $ROOT/bench.py --dtype $dt --no-cpu-baseline --no-postproc --steps 1 --warmup 1 > /dev/null 2> $ROOT/$OUT/pmc_f_$dt.err)
-  (cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_w_$dt -o pmc -- python $ROOT/bench.py --dtype $dt --no-cpu-baseline --no-postproc --steps 1 --warmup 1 > /dev/null 2> $ROOT/$OUT/pmc_w_$dt.err)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_$dt -o prof -- python $ROOT/bench.py --dtype $dt --no-cpu-baseline --no-extras > $ROOT/$OUT/bench_${dt}_under_rocprof.json 2> $ROOT/$OUT/rocprof_$dt.err)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_f_$dt -o pmc -- python $ROOT/bench.py --dtype $dt --no-cpu-baseline --no-extras --no-postproc --steps 1 --warmup 1 > /dev/null 2> $ROOT/$OUT/pmc_f_$dt.err)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_w_$dt -o pmc -- python $ROOT/bench.py --dtype $dt --no-cpu-baseline --no-extras --no-postproc --steps 1 --warmup 1 > /dev/null 2> $ROOT/$OUT/pmc_w_$dt.err)
   find $OUT/prof_$dt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$dt.csv \;
   # counter CSVs are large: keep only the per-class summary
   python tools/pmc_traffic.py $OUT/pmc_f_$dt $OUT/pmc_w_$dt ../$OUT/traffic_$dt.json > $OUT/traffic_$dt.txt 2>&1
   rm -rf $OUT/pmc_f_$dt $OUT/pmc_w_$dt
   find $OUT/prof_$dt -name "*kernel_trace.csv" -delete
 done
-python tools/bench_cli.py --tiles 128 --batch 16 > $OUT/bench_cli.json 2> $OUT/bench_cli.err
-python tools/bench_cli.py --tiles 128 --batch 32 >> $OUT/bench_cli.json 2>> $OUT/bench_cli.err
-cat $OUT/rc.txt; cat $OUT/bench_cli.json
+python tools/bench_slide.py --tiles 1024 --batch 16 > $OUT/slide_1024_b16.json 2> $OUT/slide_1024_b16.err
+python tools/bench_slide.py --tiles 1024 --batch 64 > $OUT/slide_1024_b64.json 2> $OUT/slide_1024_b64.err
+python tools/bench_slide.py --tiles 1024 --batch 16 --ranks 2 > $OUT/slide_1024_b16_2ranks.json 2> $OUT/slide_1024_b16_2ranks.err
+cat $OUT/rc.txt; cat $OUT/slide_1024_b16.json $OUT/slide_1024_b64.json $OUT/slide_1024_b16_2ranks.json
