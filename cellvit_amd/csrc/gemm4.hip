@@ -100,10 +100,16 @@ __device__ __forceinline__ void g4_dma(const unsigned (&a_voff)[8], const unsign
 template <int KIND, int SCHED, int BUF, int ROW, int SLOT, bool RD, bool DMA>
 __device__ __forceinline__ void g4_slot(half8_t (&FA)[2][8], half8_t (&FW)[2][8], const unsigned (&a_ad)[2], const unsigned (&w_ad)[2],
                                         const unsigned (&a_voff)[8], const unsigned (&w_voff)[8], const unsigned char* a_base,
-                                        const unsigned char* w_base, const unsigned lds_wave) {
+                                        const unsigned char* w_base, const unsigned lds_wave, const unsigned char* pa_base,
+                                        const unsigned char* pw_base) {
     constexpr int s = ROW * 4 + SLOT;
     if constexpr (KIND == 0) {
         if constexpr (s < 16 && RD) g4_read<1, BUF, s>(FA, FW, a_ad[1], w_ad[1]);
+        // SCHED 4: the second half of the PREVIOUS step B's K tile (pieces 8..15, stage BUF ^ 1) is issued here, in slots 16..31
+        if constexpr (SCHED == 4 && s >= 16 && (s & 1) == 0 && DMA) g4_dma<BUF ^ 1, 8 + ((s - 16) >> 1)>(a_voff, w_voff, pa_base, pw_base, lds_wave);
+    } else if constexpr (SCHED == 4) {
+        if constexpr ((s & 1) == 0 && RD) g4_read<0, BUF ^ 1, (s >> 1)>(FA, FW, a_ad[0], w_ad[0]);
+        if constexpr ((s & 3) == 1 && DMA) g4_dma<BUF, (s >> 2)>(a_voff, w_voff, a_base, w_base, lds_wave);      // pieces 0..7
     } else {
         constexpr int r = SCHED == 0 ? (s < 16 ? s : -1) : SCHED == 1 ? ((s & 1) == 0 ? s >> 1 : -1) : SCHED == 2 ? (s < 16 ? s : -1)
                                                                                                     : (s >= 16 ? s - 16 : -1);
@@ -117,13 +123,13 @@ __device__ __forceinline__ void g4_slot(half8_t (&FA)[2][8], half8_t (&FW)[2][8]
 #define G4_ROW(KIND, SET, BUF, ROW, RD, DMA)                                                                                    \
     do {                                                                                                               \
         G4_MM(SET, ROW, 0); G4_MM(SET, ROW, 1);                                                                        \
-        g4_slot<KIND, SCHED, BUF, ROW, 0, RD, DMA>(FA, FW, a_ad, w_ad, a_voff, w_voff, a_base, w_base, lds_wave); G4_SB(); \
+        g4_slot<KIND, SCHED, BUF, ROW, 0, RD, DMA>(FA, FW, a_ad, w_ad, a_voff, w_voff, a_base, w_base, lds_wave, pa_base, pw_base); G4_SB(); \
         G4_MM(SET, ROW, 2); G4_MM(SET, ROW, 3);                                                                        \
-        g4_slot<KIND, SCHED, BUF, ROW, 1, RD, DMA>(FA, FW, a_ad, w_ad, a_voff, w_voff, a_base, w_base, lds_wave); G4_SB(); \
+        g4_slot<KIND, SCHED, BUF, ROW, 1, RD, DMA>(FA, FW, a_ad, w_ad, a_voff, w_voff, a_base, w_base, lds_wave, pa_base, pw_base); G4_SB(); \
         G4_MM(SET, ROW, 4); G4_MM(SET, ROW, 5);                                                                        \
-        g4_slot<KIND, SCHED, BUF, ROW, 2, RD, DMA>(FA, FW, a_ad, w_ad, a_voff, w_voff, a_base, w_base, lds_wave); G4_SB(); \
+        g4_slot<KIND, SCHED, BUF, ROW, 2, RD, DMA>(FA, FW, a_ad, w_ad, a_voff, w_voff, a_base, w_base, lds_wave, pa_base, pw_base); G4_SB(); \
         G4_MM(SET, ROW, 6); G4_MM(SET, ROW, 7);                                                                        \
-        g4_slot<KIND, SCHED, BUF, ROW, 3, RD, DMA>(FA, FW, a_ad, w_ad, a_voff, w_voff, a_base, w_base, lds_wave); G4_SB(); \
+        g4_slot<KIND, SCHED, BUF, ROW, 3, RD, DMA>(FA, FW, a_ad, w_ad, a_voff, w_voff, a_base, w_base, lds_wave, pa_base, pw_base); G4_SB(); \
     } while (0)
 
 #define G4_STEP(KIND, SET, BUF, RD, DMA)                                                                                        \
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(G4_NT) void gemm4_kernel(const GemmParams p) {
     // operands are in flight during the epilogue.  (After the workgroup's last tile the "next" tile is that tile again: two
     // K tiles and 16 fragments are fetched into nothing, once per workgroup.)
     half8_t FA[2][8], FW[2][8];
+    const unsigned char* pa_carry = nullptr; const unsigned char* pw_carry = nullptr;   // SCHED 4: bases of the K tile the previous step B began
     int m0, n0; bool swap;
     int tile = blockIdx.x;
     int slot = 0;
@@ -234,6 +241,7 @@ __global__ __launch_bounds__(G4_NT) void gemm4_kernel(const GemmParams p) {
         G4_D(8); G4_D(9); G4_D(10); G4_D(11); G4_D(12); G4_D(13); G4_D(14); G4_D(15);
 #undef G4_D
     }
+    pa_carry = k_base(Ab, 1); pw_carry = k_base(Wb, 1);   // (SCHED 4 re-issues the second half of K tile 1 in its first step A: harmless)
     G4_VMCNT(16);                                   // K tile 0 (and the bias) has landed; tile 1 may still be in flight
     G4_SB(); __builtin_amdgcn_s_barrier(); G4_SB();
     for (; tile < ntiles; tile += gridDim.x, slot ^= 1) {
@@ -261,6 +269,8 @@ __global__ __launch_bounds__(G4_NT) void gemm4_kernel(const GemmParams p) {
     do {                                                                                                               \
         const unsigned char* a_base = k_base(Ab, KT2);                                                                 \
         const unsigned char* w_base = k_base(Wb, KT2);                                                                 \
+        const unsigned char* pa_base = pa_carry; const unsigned char* pw_base = pw_carry;                              \
+        pa_carry = a_base; pw_carry = w_base;                                                                          \
         G4_WAIT_SET(0); G4_SB();                                                                                       \
         G4_STEP(0, 0, BUF, !(ABL & 2), !(ABL & 1));                                                                    \
         G4_VMCNT(0);                                                                                                   \
@@ -363,6 +373,7 @@ int launch_gemm4(const GemmParams& p, int sched, hipStream_t stream) {
             case 0: return launch4<OUT_LINEAR, 0>(p, stream);
             case 2: return launch4<OUT_LINEAR, 2>(p, stream);
             case 3: return launch4<OUT_LINEAR, 3>(p, stream);
+            case 4: return launch4<OUT_LINEAR, 4>(p, stream);      // DMA spread over both K steps (linear shapes without row remap only)
             case 21: return launch4<OUT_LINEAR, 1, 1>(p, stream);      // work-skipping (wrong results): no operand DMA in the loop,
             case 22: return launch4<OUT_LINEAR, 1, 2>(p, stream);      // no fragment reads,
             case 23: return launch4<OUT_LINEAR, 1, 3>(p, stream);      // neither,
