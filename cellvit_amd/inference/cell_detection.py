@@ -343,14 +343,29 @@ class CellSegmentationInference:
     def run_tiles(self, wsi: PatchedSlide, tile_ids: List[int], batch_size: int, patch_size: int = 1024,
                   overlap: int = 64, num_workers: Optional[int] = None) -> Tuple[SlideCells, List[str], dict]:
         """The tile loop (cell_detection.py:306-421) for one rank's tiles.  Per batch: raw u8 tiles -> forward (HIP) ->
-        post-processing on the argmax planes the forward wrote (HIP) -> cell-token pooling (HIP); then ONE device->host
-        copy of the record / contour arrays.  Host work of batch k (array unpacking) overlaps the GPU work of k+1."""
+        post-processing on the argmax planes the forward wrote (HIP) -> cell-token pooling (HIP); then the record / contour
+        arrays go to pinned host buffers on a copy stream.  Host work of batch k (array unpacking) overlaps the GPU work of k+1."""
         nuclei_types = self.run_conf["dataset_config"]["nuclei_types"]
         obj, ks = _params(int(wsi.metadata["magnification"]))
         parts: List[SlideCells] = []
         processed: List[str] = []
         stats = {"tiles": 0, "t_loop": 0.0}
         import time
+
+        # Device -> host hand-over of a batch's record / contour arrays: asynchronous copies into pinned buffers on a SECOND stream
+        # that waits only for that batch's own event.  (Copies issued on the compute stream are ordered behind the NEXT batch's
+        # kernels, which were enqueued first: the host then waited a whole batch for them and unpacked with the GPU idle —
+        # measured: 86 tiles/s through this loop against 97 for the same kernels in bench.py.)
+        copy_stream = torch.cuda.Stream(self.device)
+        pinned: List[Optional[tuple]] = [None, None]          # two sets: batch k is unpacked while batch k+1 is copied
+        turn = [0]
+
+        def pinned_like(i, *tensors):
+            have = pinned[i]
+            if have is None or any(h.shape != t.shape or h.dtype != t.dtype for h, t in zip(have, tensors)):
+                have = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors)
+                pinned[i] = have
+            return have
 
         def enqueue(ids, x_u8, mds):
             pred = self.model.forward_u8(x_u8, self.mean, self.std, retrieve_tokens=True)
@@ -360,26 +375,51 @@ class CellSegmentationInference:
             pooled, cap = pool_cell_tokens_fixed(pred["tokens"], recs, n_recs, self.model.patch_size, cap=self.pool_cap)
             ev = torch.cuda.Event()
             ev.record()
-            return ids, mds, recs, n_recs, contours, n_pts, pooled, cap, ev, pred["tokens"]
+            host = pinned_like(turn[0], recs, n_recs, contours, n_pts)
+            turn[0] ^= 1
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ev)
+                for h, t in zip(host, (recs, n_recs, contours, n_pts)):
+                    h.copy_(t, non_blocking=True)
+                ev_copy = torch.cuda.Event()
+                ev_copy.record(copy_stream)
+            return ids, mds, recs, n_recs, contours, n_pts, pooled, cap, ev_copy, pred["tokens"], host
 
         def finish(job):
-            ids, mds, recs, n_recs, contours, n_pts, pooled, cap, ev, tokens = job
-            ev.synchronize()
-            nr, npt = n_recs.cpu().numpy(), n_pts.cpu().numpy()
+            ids, mds, recs, n_recs, contours, n_pts, pooled, cap, ev_copy, tokens, host = job
+            ev_copy.synchronize()                                  # this batch's copies only — the next batch keeps the GPU busy
+            recs_h, nr_h, pts_all, npt_h = host
+            nr, npt = nr_h.numpy().copy(), npt_h.numpy().copy()
             check_capacity(recs, nr, contours, npt)
             if (nr > cap).any():                                   # rare: a tile with more cells than fixed pooling slots
                 exact, off = pool_cell_tokens(tokens, recs, n_recs, self.model.patch_size)
-                pooled = [exact[int(off[b]):int(off[b]) + int(nr[b])] for b in range(len(ids))]   # per-tile rows, as pooled[b] below
+                pooled = [exact[int(off[b]):int(off[b]) + int(nr[b])] for b in range(len(ids))]   # per-tile rows
+                copy_stream.wait_stream(torch.cuda.current_stream(self.device))     # (this pass ran on the compute stream)
             mx_r, mx_p = int(nr.max()), int(npt.max())
-            rec_h = recs[:, :mx_r].cpu().numpy().view(REC_DTYPE).reshape(len(ids), mx_r)
-            pts_h = contours[:, :mx_p].cpu().numpy()
+            rec_h = recs_h[:, :mx_r].numpy().view(REC_DTYPE).reshape(len(ids), mx_r)
+            pts_h = pts_all[:, :mx_p].numpy()
+            tiles_out, rows = [], []
             for b, (tile, md) in enumerate(zip(ids, mds)):
                 row, col = int(md["row"]), int(md["col"])
                 processed.append(f"{row}_{col}")
                 ir, fr, ct, keep = SlideCells.from_tile_records(rec_h[b, :nr[b]], pts_h[b], tile, row, col,
                                                                 nuclei_types["Background"], patch_size, overlap)
-                sel = torch.as_tensor(keep, dtype=torch.long, device=pooled[b].device)
-                parts.append(SlideCells(ir, fr, ct, pooled[b].index_select(0, sel)))
+                tiles_out.append((ir, fr, ct, len(keep)))
+                rows.append(keep if isinstance(pooled, list) else keep + b * cap)
+            # token rows of the kept cells: ONE gather per batch, on the copy stream.  (An index upload on the compute stream is
+            # a synchronous copy ordered behind the next batch's kernels: the host sat out a whole batch there, then unpacked
+            # with the GPU idle — 12 % of the loop.)
+            with torch.cuda.stream(copy_stream):
+                if isinstance(pooled, list):
+                    tok = torch.cat([pooled[b].index_select(0, torch.as_tensor(rows[b], dtype=torch.long, device=pooled[b].device))
+                                     for b in range(len(ids))]) if len(ids) else None
+                else:
+                    idx = torch.as_tensor(np.concatenate(rows) if rows else np.zeros(0, np.int64), dtype=torch.long, device=pooled.device)
+                    tok = pooled.reshape(-1, pooled.shape[-1]).index_select(0, idx)
+            o = 0
+            for ir, fr, ct, n in tiles_out:
+                parts.append(SlideCells(ir, fr, ct, tok[o:o + n]))
+                o += n
             stats["tiles"] += len(ids)
 
         t0 = time.perf_counter()
@@ -392,11 +432,25 @@ class CellSegmentationInference:
                 pending = job
             if pending is not None:
                 finish(pending)
+            copy_stream.synchronize()
         stats["t_loop"] = time.perf_counter() - t0
         return SlideCells.concat(parts), processed, stats
 
+    def wait_for_writers(self) -> None:
+        """Join the writer thread of the previous slide (see `process_wsi(..., defer_write=True)`); re-raises its error."""
+        th = getattr(self, "_writer", None)
+        if th is not None:
+            th.join()
+            self._writer = None
+            err = getattr(self, "_writer_error", None)
+            self._writer_error = None
+            if err is not None:
+                raise err
+
     def process_wsi(self, wsi: PatchedSlide, subdir_name: Optional[str] = None, patch_size: int = 1024,
-                    overlap: int = 64, batch_size: int = 8, geojson: bool = False) -> dict:
+                    overlap: int = 64, batch_size: int = 8, geojson: bool = False, defer_write: bool = False) -> dict:
+        """`defer_write`: hand the files of this slide to a writer thread and return (process_dataset: the files of slide k are
+        written — mostly outside the GIL — while the tile loop of slide k+1 runs); `wait_for_writers()` joins it."""
         import torch.distributed as dist
         dd = dist.is_available() and dist.is_initialized()
         rank = dist.get_rank() if dd else 0
@@ -419,9 +473,22 @@ class CellSegmentationInference:
             processed = sorted((p for part in gathered for p in part), key=lambda k: order.get(k, 1 << 30))
         import time
         t0 = time.perf_counter()
+        self.wait_for_writers()                                   # at most one slide's files in flight
         if rank == 0:
-            write_outputs(outdir, wsi.metadata, processed, nuclei_types, allc, geojson, wsi.metadata["patch_size"],
-                          wsi.metadata["downsampling"], overlap)
+            wargs = (outdir, wsi.metadata, processed, nuclei_types, allc, geojson, wsi.metadata["patch_size"],
+                     wsi.metadata["downsampling"], overlap)
+            if defer_write:
+                import threading
+
+                def _write():
+                    try:
+                        write_outputs(*wargs)
+                    except BaseException as e:      # noqa: BLE001  (re-raised by wait_for_writers)
+                        self._writer_error = e
+                self._writer = threading.Thread(target=_write, name="cellvit-writers")
+                self._writer.start()
+            else:
+                write_outputs(*wargs)
         timings["write_s"] = time.perf_counter() - t0
         stats.update({"n_cells": len(allc), "cells_before_cleaning": len(local), "outdir": str(outdir), **timings})
         return stats
@@ -453,7 +520,7 @@ def write_outputs(outdir: Path, wsi_metadata: dict, processed: List[str], nuclei
     import ctypes as C
     import threading
     from .. import _lib
-    from ..datamodel import make_cell_graph
+    from ..datamodel import save_cell_graph
     lib = _lib.load()
     n = len(allc)
     g = allc.geometry(patch_size, downsampling, overlap)
@@ -478,12 +545,11 @@ def write_outputs(outdir: Path, wsi_metadata: dict, processed: List[str], nuclei
     if n:
         D = allc.tokens.shape[1] if allc.tokens is not None else 0
         x = allc.tokens.float().cpu() if allc.tokens is not None else torch.zeros((n, D))
-        lens = np.diff(g["ct_off"]).tolist()
-        graph = make_cell_graph(
-            x=x, positions=torch.from_numpy(g["centroid"].astype(np.float32)),
-            contours=list(torch.from_numpy(g["contour"].astype(np.float32)).split(lens)),     # views of ONE storage (`torch.Tensor(list)` per cell in the reference)
-            metadata={"wsi_metadata": wsi_metadata, "nuclei_types": nuclei_types})
-        torch.save(graph, outdir / "cells.pt")
+        # one [len_k, 2] float32 view per cell of ONE contour tensor (`torch.Tensor(list)` per cell in the reference); the list's
+        # pickle records are generated in bulk (datamodel.save_cell_graph: 0.24 s instead of 2.8 s per 10^5 cells)
+        save_cell_graph(outdir / "cells.pt", x, torch.from_numpy(g["centroid"].astype(np.float32)),
+                        torch.from_numpy(g["contour"].astype(np.float32)), np.diff(g["ct_off"]).tolist(),
+                        {"wsi_metadata": wsi_metadata, "nuclei_types": nuclei_types})
     if geojson:
         cells_all = allc.to_dicts(patch_size, downsampling, overlap)
         with open(outdir / "cells.geojson", "w") as f:
@@ -585,7 +651,8 @@ def main(argv=None) -> None:
                 continue
             slide = PatchedSlide(Path(n).stem, str(pdir))
             check_wsi(slide, conf["magnification"])
-            inf.process_wsi(slide, conf["outdir_subdir"], batch_size=conf["batch_size"], geojson=conf["geojson"])
+            inf.process_wsi(slide, conf["outdir_subdir"], batch_size=conf["batch_size"], geojson=conf["geojson"], defer_write=True)
+        inf.wait_for_writers()
     else:
         raise ValueError("Unknown command")
 

@@ -307,6 +307,46 @@ def test_cells_pt_wire_format(tmp_path):
     assert torch.equal(back.x, g.x) and len(back.contours) == 3 and back.metadata["wsi_metadata"] == {"a": 1}
 
 
+def test_fast_cells_pt_writer_equals_torch_save_of_the_per_cell_list(tmp_path):
+    """datamodel.save_cell_graph generates the pickle records of the contour list in bulk: the file must load (plain torch.load)
+    to exactly what torch.save of the reference's per-cell construction loads to, and fall back to torch.save outside its ranges."""
+    from cellvit_amd.datamodel import make_cell_graph, save_cell_graph
+    rng = np.random.default_rng(2)
+    n = 3000
+    lens = rng.integers(3, 300, n).tolist()
+    pts = torch.from_numpy(rng.integers(-50, 200000, (sum(lens), 2)).astype(np.float32))
+    x, pos = torch.randn(n, 8), torch.randn(n, 2)
+    meta = {"wsi_metadata": {"magnification": 40}, "nuclei_types": {"Background": 0, "Neoplastic": 1}}
+    assert save_cell_graph(tmp_path / "fast.pt", x, pos, pts, lens, meta) == "fast"
+    torch.save(make_cell_graph(x=x, positions=pos, contours=[torch.Tensor(c.tolist()) for c in pts.split(lens)], metadata=meta),
+               tmp_path / "ref.pt")
+    a = torch.load(tmp_path / "fast.pt", weights_only=False)
+    b = torch.load(tmp_path / "ref.pt", weights_only=False)
+    assert type(a) is type(b) and a.metadata == b.metadata and torch.equal(a.x, b.x) and torch.equal(a.positions, b.positions)
+    assert len(a.contours) == n and all(torch.equal(u, v) and u.is_contiguous() for u, v in zip(a.contours, b.contours))
+    assert save_cell_graph(tmp_path / "one.pt", x[:1], pos[:1], pts[:lens[0]], lens[:1], meta) == "torch.save"    # a single cell
+    long = [70000, 5]
+    big = torch.zeros((sum(long), 2))
+    assert save_cell_graph(tmp_path / "long.pt", x[:2], pos[:2], big, long, meta) == "torch.save"                 # a contour >= 65536 points
+    assert [c.shape[0] for c in torch.load(tmp_path / "long.pt", weights_only=False).contours] == long
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/cell_segmentation"), reason="reference tree not present")
+def test_fast_cells_pt_loads_with_the_reference_classes(tmp_path):
+    import subprocess
+    import sys
+    from cellvit_amd.datamodel import save_cell_graph
+    save_cell_graph(tmp_path / "cells.pt", torch.arange(12.).reshape(3, 4), torch.ones(3, 2), torch.arange(24.).reshape(12, 2), [3, 4, 5],
+                    {"nuclei_types": {"Background": 0}})
+    code = ("import sys, torch; sys.path.insert(0, '/root/reference');"
+            "from cell_segmentation.datasets.cell_graph_datamodel import CellGraphDataWSI;"
+            f"g = torch.load(r'{tmp_path / 'cells.pt'}', weights_only=False);"
+            "assert isinstance(g, CellGraphDataWSI), type(g);"
+            "assert [tuple(c.shape) for c in g.contours] == [(3, 2), (4, 2), (5, 2)] and float(g.contours[2][0, 0]) == 14.0; print('REF-OK')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert "REF-OK" in r.stdout, r.stderr[-2000:]
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/cell_segmentation"), reason="reference tree not present")
 def test_cells_pt_loads_with_the_reference_classes(tmp_path):
     """Development container only: a file written here unpickles in a fresh interpreter that has ONLY the reference on its

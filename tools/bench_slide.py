@@ -83,7 +83,7 @@ def build_slide(tmp, tiles, model, with_ckpt=True):
     return os.path.join(tmp, "ckpt.pth"), slide
 
 
-def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batches=2, world_seed=3, real_model=None):
+def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batches=2, world_seed=3, real_model=None, slides=1):
     """One slide through process_wsi on this process's rank; returns the stats dict of rank 0 (None on other ranks).
     `real_model`: an already built cellvit_amd model (bench.py's); otherwise a seeded checkpoint is written and loaded
     through the CLI's own checkpoint path."""
@@ -117,6 +117,17 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
     t0 = time.perf_counter()
     stats = inf.process_wsi(wsi, batch_size=batch, geojson=geojson)
     total = time.perf_counter() - t0
+    dataset = None
+    if slides > 1:        # process_dataset mode: the files of slide k are written while the tile loop of slide k+1 runs
+        t1 = time.perf_counter()
+        loops = []
+        for k in range(slides):
+            st = inf.process_wsi(wsi, subdir_name=f"s{k}", batch_size=batch, geojson=geojson, defer_write=True)
+            loops.append(st["tiles"] / st["t_loop"])
+        inf.wait_for_writers()
+        dt = time.perf_counter() - t1
+        dataset = {"slides": slides, "total_s": dt, "s_per_slide": dt / slides, "tiles_per_s": slides * tiles / dt,
+                   "tile_loop_tiles_per_s_per_slide": loops}
     out_bytes = sum(os.path.getsize(os.path.join(stats["outdir"], f)) for f in os.listdir(stats["outdir"])) if rank == 0 else 0
     if rank != 0:
         return None
@@ -126,7 +137,7 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
             "margin_records": stats["margin_records"], "margin_kept": stats["margin_kept"],
             "exchange_s": stats["exchange_s"], "stitch_s": stats["stitch_s"], "to_dicts_s": stats["to_dicts_s"],
             "write_s": stats["write_s"], "slide_total_s": total, "slide_tiles_per_s": tiles / total,
-            "output_MB": out_bytes / 1e6, "host_cpus": os.cpu_count()}
+            "output_MB": out_bytes / 1e6, "host_cpus": os.cpu_count(), "dataset_mode": dataset}
 
 
 def main():
@@ -137,6 +148,7 @@ def main():
     ap.add_argument("--ranks", type=int, default=1)
     ap.add_argument("--geojson", action="store_true")
     ap.add_argument("--tmp", default=None)
+    ap.add_argument("--slides", type=int, default=1, help="> 1: additionally run that many slides back to back with deferred writers")
     args = ap.parse_args()
     if args.ranks > 1 and "WORLD_SIZE" not in os.environ:
         import socket
@@ -154,7 +166,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")                   # all ranks share the box's one GPU: host-side exchange
     torch.cuda.set_device(0)
-    rec = run(args.tiles, args.batch, args.model, args.geojson, args.tmp)
+    rec = run(args.tiles, args.batch, args.model, args.geojson, args.tmp, slides=args.slides)
     if rec is not None:
         print(json.dumps(rec))
     if dist.is_initialized():
