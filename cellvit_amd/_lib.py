@@ -11,6 +11,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcellvit_amd.so")
+if os.environ.get("CVA_LIB") == "abl":      # experiment flavour (`python -m cellvit_amd.build --ablation`): the one that honours CVA_* switches
+    LIB_PATH = os.path.join(HERE, "libcellvit_amd_abl.so")
 
 CV_OK, CV_ERR_INVALID, CV_ERR_HIP, CV_ERR_STATE, CV_ERR_SHAPE, CV_ERR_UNSUPPORTED, CV_ERR_MISSING = range(7)
 DTYPE_F16, DTYPE_F32, DTYPE_F8 = 0, 1, 2
@@ -74,6 +76,7 @@ SYMBOLS = {
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cv_op_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cv_op_deconv_block": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_void_p]),
 }
 
 SYMBOLS.update({

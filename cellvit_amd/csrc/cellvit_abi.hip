@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -87,6 +88,10 @@ struct ConvW {
     void* Wkm = nullptr;     // fp16 engines, layers the implicit-GEMM convolution can take: the same filter in (64-channel chunk, tap, channel) K order
 };
 struct ConvTW { void* W = nullptr; float* bias4 = nullptr; int Cin = 0, Cout = 0, ldw = 0; };
+// Deconv2DBlock (ConvTranspose2d k2 s2 -> Conv2d 3x3 -> BatchNorm -> ReLU, models/segmentation/cell_segmentation/utils.py:46-86) composed into ONE contraction over
+// the block's INPUT pixels (fp16 engines, Cout % 256 == 0; gemm8.hip launch_gemm8_deconv): W [4*Cout][(64-ch chunk, 2x2 input pixel, ch)],
+// bias4 = interior bias per output parity, btab = the nine border cases.
+struct DeconvCompW { void* W = nullptr; float* bias4 = nullptr; float* btab = nullptr; int Cin = 0, Cout = 0; };
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct HeadW { float* W = nullptr; float* b = nullptr; int n_out = 0; };
 struct BlockW {
@@ -121,9 +126,9 @@ struct cv_handle {
     LNW final_norm; LinearW vit_head;                 // ViT
     LinearW neck0; LNW neck1; ConvW neck2; LNW neck3; LinearW cls_head;   // SAM
     ConvW dec0[2];
-    ConvTW dec1_t[3]; ConvW dec1_c[3];
-    ConvTW dec2_t[2]; ConvW dec2_c[2];
-    ConvTW dec3_t[1]; ConvW dec3_c[1];
+    ConvTW dec1_t[3]; ConvW dec1_c[3]; DeconvCompW dec1_k[3];
+    ConvTW dec2_t[2]; ConvW dec2_c[2]; DeconvCompW dec2_k[2];
+    ConvTW dec3_t[1]; ConvW dec3_c[1]; DeconvCompW dec3_k[1];
     BranchW branch[3];
     // geometry + workspace
     Geometry g;
@@ -345,12 +350,108 @@ int pack_convT(cv_handle* h, const std::string& key, int Cin, int Cout, ConvTW* 
     return CV_OK;
 }
 
+// Composition of a Deconv2DBlock's two linear maps.  With up = ConvT(z) + bt and y = W3' * up + b3' (W3', b3': BatchNorm folded),
+// output pixel (Y, X) = (2y + py, 2x + px) reads up at (Y + ky - 1, X + kx - 1), which is input pixel
+// (y + floor((py + ky - 1) / 2), x + floor((px + kx - 1) / 2)) through transposed-convolution tap ((py + ky - 1) & 1, (px + kx - 1) & 1):
+//   Wc[p][co][(s, t)][cz] = sum over the (ky, kx) that map to input offset (py - 1 + s, px - 1 + t) of sum_cu W3'[co][cu][ky][kx] * Wt[cz][cu][dy][dx]
+// The 36 products [Cout, Cup] x [Cup, Cz] run as fp32 GEMMs of the parity engine on the device (12 GMAC for 1280 -> 512: seconds on
+// the host), are read back, re-ordered to the kernel's K order and rounded ONCE to fp16.  Bias: b3' + sum over the taps INSIDE the
+// image of W3'[.,.,ky,kx] . bt — nine (row case, column case) tables; the interior one is the staged bias of every column tile.
+int pack_deconv_comp(cv_handle* h, const std::string& p, int Cin, int Cout, DeconvCompW* out) {
+    if (is_f32(h->cfg.compute_dtype) || Cout % 256 || Cin % 64) return CV_OK;       // not a shape the composed kernel takes
+    static const int use = cva_env_int("CVA_DECONV_COMP", 1);                        // ablation builds: 0 = the two-launch form (A/B)
+    if (!use) return CV_OK;
+    const int Cup = Cout;
+    const HostTensor* wt = find(h, p + ".block.0.weight", {Cin, Cup, 2, 2}); CVA_NEED(wt);
+    const HostTensor* bt = find(h, p + ".block.0.bias", {Cup}); CVA_NEED(bt);
+    const HostTensor* w3 = find(h, p + ".block.1.weight", {Cout, Cup, 3, 3}); CVA_NEED(w3);
+    const HostTensor* b3 = find(h, p + ".block.1.bias", {Cout}); CVA_NEED(b3);
+    const HostTensor* g = find(h, p + ".block.2.weight", {Cout}); CVA_NEED(g);
+    const HostTensor* be = find(h, p + ".block.2.bias", {Cout}); CVA_NEED(be);
+    const HostTensor* mu = find(h, p + ".block.2.running_mean", {Cout}); CVA_NEED(mu);
+    const HostTensor* var = find(h, p + ".block.2.running_var", {Cout}); CVA_NEED(var);
+    // folded 3x3 filters per tap [9][Cout][Cup], transposed-convolution taps [4][Cin][Cup] (both K = Cup contiguous), bias tables
+    std::vector<float> w3f((size_t)9 * Cout * Cup), wtt((size_t)4 * Cin * Cup);
+    std::vector<double> b3f(Cout), tb((size_t)9 * Cout, 0.0);
+    for (int co = 0; co < Cout; ++co) {
+        const double scale = (double)g->data[co] / std::sqrt((double)var->data[co] + BN_EPS);
+        b3f[co] = (double)b3->data[co] * scale + ((double)be->data[co] - (double)mu->data[co] * scale);
+        for (int cu = 0; cu < Cup; ++cu)
+            for (int t = 0; t < 9; ++t) {
+                const double w = (double)w3->data[((size_t)co * Cup + cu) * 9 + t] * scale;
+                w3f[((size_t)t * Cout + co) * Cup + cu] = (float)w;
+                tb[(size_t)t * Cout + co] += w * (double)bt->data[cu];
+            }
+    }
+    for (int cz = 0; cz < Cin; ++cz)
+        for (int cu = 0; cu < Cup; ++cu)
+            for (int dd = 0; dd < 4; ++dd) wtt[((size_t)dd * Cin + cz) * Cup + cu] = wt->data[((size_t)cz * Cup + cu) * 4 + dd];
+    std::vector<float> btab((size_t)9 * Cout), b4((size_t)4 * Cout);
+    for (int rc = 0; rc < 3; ++rc)
+        for (int cc = 0; cc < 3; ++cc)
+            for (int co = 0; co < Cout; ++co) {
+                double v = b3f[co];
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        if ((rc == 0 && ky == 0) || (rc == 2 && ky == 2) || (cc == 0 && kx == 0) || (cc == 2 && kx == 2)) continue;
+                        v += tb[(size_t)(ky * 3 + kx) * Cout + co];
+                    }
+                btab[(size_t)(rc * 3 + cc) * Cout + co] = (float)v;
+            }
+    for (int dd = 0; dd < 4; ++dd) memcpy(&b4[(size_t)dd * Cout], &btab[(size_t)4 * Cout], (size_t)Cout * sizeof(float));
+
+    float *d3 = nullptr, *dt = nullptr, *dc = nullptr;
+    const size_t n3 = w3f.size(), nt = wtt.size(), nc = (size_t)16 * Cout * Cin;
+    auto cleanup = [&]() { (void)hipFree(d3); (void)hipFree(dt); (void)hipFree(dc); };
+    if (hipMalloc(&d3, n3 * 4) != hipSuccess || hipMalloc(&dt, nt * 4) != hipSuccess || hipMalloc(&dc, nc * 4) != hipSuccess) {
+        cleanup(); cva_set_error("out of device memory composing '%s'", p.c_str()); return CV_ERR_HIP;
+    }
+    int rc = CV_OK;
+    if (hipMemcpy(d3, w3f.data(), n3 * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dt, wtt.data(), nt * 4, hipMemcpyHostToDevice) != hipSuccess) rc = CV_ERR_HIP;
+    bool touched[16] = {};
+    for (int par = 0; par < 4 && rc == CV_OK; ++par)
+        for (int ky = 0; ky < 3 && rc == CV_OK; ++ky)
+            for (int kx = 0; kx < 3 && rc == CV_OK; ++kx) {
+                const int py = par >> 1, px = par & 1, uy = py + ky - 1, ux = px + kx - 1;
+                const int ay = uy < 0 ? -1 : uy >> 1, ax = ux < 0 ? -1 : ux >> 1, dy = uy & 1, dx = ux & 1;
+                const int t4 = (ay + 1 - py) * 2 + (ax + 1 - px), slot = par * 4 + t4;
+                GemmParams q{};
+                q.M = Cout; q.N = Cin; q.K = Cup; q.lda = Cup; q.ldw = Cup;
+                q.A = d3 + (size_t)(ky * 3 + kx) * Cout * Cup; q.W = dt + (size_t)(dy * 2 + dx) * Cin * Cup;
+                q.out = dc + (size_t)slot * Cout * Cin; q.ldc = Cin; q.out_f32 = 1; q.out_mode = OUT_LINEAR; q.act = ACT_NONE;
+                if (touched[slot]) { q.res = reinterpret_cast<const float*>(q.out); q.ldres = Cin; }
+                touched[slot] = true;
+                if (launch_gemm<float>(q, A_LINEAR, nullptr)) rc = CV_ERR_HIP;
+            }
+    std::vector<float> hc;
+    if (rc == CV_OK) {
+        hc.resize(nc);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(hc.data(), dc, nc * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = CV_ERR_HIP;
+    }
+    cleanup();
+    if (rc != CV_OK) { cva_set_error("composing '%s' on the device failed", p.c_str()); return rc; }
+    const int K = 4 * Cin, chunks = Cin / 64;
+    std::vector<float> wk((size_t)4 * Cout * K);
+    for (int par = 0; par < 4; ++par)
+        for (int co = 0; co < Cout; ++co)
+            for (int ch = 0; ch < chunks; ++ch)
+                for (int t4 = 0; t4 < 4; ++t4)
+                    memcpy(&wk[((size_t)par * Cout + co) * K + ((size_t)ch * 4 + t4) * 64],
+                           &hc[((size_t)(par * 4 + t4) * Cout + co) * Cin + (size_t)ch * 64], 64 * sizeof(float));
+    out->Cin = Cin; out->Cout = Cout;
+    CVA_TRY(upload_matrix(h, wk.data(), 4 * Cout, K, K, &out->W));
+    CVA_TRY(upload_f32(h, b4.data(), b4.size(), &out->bias4));
+    CVA_TRY(upload_f32(h, btab.data(), btab.size(), &out->btab));
+    return CV_OK;
+}
+
 int pack_conv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvW* out, int Cpad = 0) {
     return pack_conv3(h, p + ".block.0", p + ".block.1", Cin, Cout, Cpad ? Cpad : Cin, true, 1, out);
 }
-int pack_deconv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvTW* t, ConvW* c) {
+int pack_deconv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvTW* t, ConvW* c, DeconvCompW* k) {
     CVA_TRY(pack_convT(h, p + ".block.0", Cin, Cout, t));
-    return pack_conv3(h, p + ".block.1", p + ".block.2", Cout, Cout, Cout, true, 1, c);
+    CVA_TRY(pack_conv3(h, p + ".block.1", p + ".block.2", Cout, Cout, Cout, true, 1, c));
+    return pack_deconv_comp(h, p, Cin, Cout, k);
 }
 
 void skip_dims(const cv_config& c, int* s11, int* s12, int* bott) {   // cellvit.py:106-113
@@ -474,6 +575,28 @@ int run_convT(const void* src, const ConvTW& w, void* out, int B, int Hs, int Ws
     const int rc = launch_gemm<T>(p, A_LINEAR, st);
     if (rc) { cva_set_error("convT launch failed (%d)", rc); return CV_ERR_HIP; }
     return CV_OK;
+}
+
+// Deconv2DBlock: the composed single launch where the block and the geometry fit it (fp16 engines), else ConvTranspose2d into `tmp`
+// and the 3x3 convolution from there.
+template <typename T>
+int run_deconv_block(const void* src, const ConvTW& t, const ConvW& c, const DeconvCompW& k, void* tmp, void* out, int B, int Hs, int Ws,
+                     hipStream_t st) {
+    if (sizeof(T) == 2 && k.W) {
+        GemmParams p{};
+        p.M = B * Hs * Ws; p.N = 4 * k.Cout; p.K = 4 * k.Cin; p.A = src; p.W = k.W; p.ldw = p.K;
+        p.H = Hs; p.Wd = Ws; p.C1 = k.Cin;
+        p.bias = k.bias4; p.comp_bias = k.btab; p.act = ACT_RELU; p.out_mode = OUT_CONVT; p.out = out;
+        int rc;
+        {
+            ProfScope ps(KC_CONV3, 2.0 * p.M * (double)p.N * p.K, st);      // executed FLOPs (the two-launch form: 2*M*4*Cout*(Cin + 9*Cout))
+            rc = launch_gemm8_deconv(p, st);
+        }
+        if (rc == 0) return CV_OK;
+        if (rc != -1) { cva_set_error("composed deconv block launch failed (%d)", rc); return CV_ERR_HIP; }
+    }
+    CVA_TRY(run_convT<T>(src, t, tmp, B, Hs, Ws, st));
+    return run_conv3<T>(tmp, c.Ctot, nullptr, 0, c, out, 0, B, 2 * Hs, 2 * Ws, st);
 }
 
 #define CVA_LAUNCH(expr) do { int _rc = (expr); if (_rc) { cva_set_error("%s failed (%d)", #expr, _rc); return CV_ERR_HIP; } } while (0)
@@ -631,20 +754,14 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
     CVA_TRY(run_conv3<T>(h->img8, h->dec0[0].Ctot, nullptr, 0, h->dec0[0], S0, 0, B, H, W, st));
     CVA_TRY(run_conv3<T>(S0, 32, nullptr, 0, h->dec0[1], h->skip[0], 0, B, H, W, st));
     // decoder1: z1 -> x8
-    CVA_TRY(run_convT<T>(h->z[0], h->dec1_t[0], S0, B, gh, gw, st));
-    CVA_TRY(run_conv3<T>(S0, s11, nullptr, 0, h->dec1_c[0], S1, 0, B, 2 * gh, 2 * gw, st));
-    CVA_TRY(run_convT<T>(S1, h->dec1_t[1], S0, B, 2 * gh, 2 * gw, st));
-    CVA_TRY(run_conv3<T>(S0, s12, nullptr, 0, h->dec1_c[1], S1, 0, B, 4 * gh, 4 * gw, st));
-    CVA_TRY(run_convT<T>(S1, h->dec1_t[2], S0, B, 4 * gh, 4 * gw, st));
-    CVA_TRY(run_conv3<T>(S0, 128, nullptr, 0, h->dec1_c[2], h->skip[1], 0, B, 8 * gh, 8 * gw, st));
+    CVA_TRY(run_deconv_block<T>(h->z[0], h->dec1_t[0], h->dec1_c[0], h->dec1_k[0], S0, S1, B, gh, gw, st));
+    CVA_TRY(run_deconv_block<T>(S1, h->dec1_t[1], h->dec1_c[1], h->dec1_k[1], S0, S2, B, 2 * gh, 2 * gw, st));
+    CVA_TRY(run_deconv_block<T>(S2, h->dec1_t[2], h->dec1_c[2], h->dec1_k[2], S0, h->skip[1], B, 4 * gh, 4 * gw, st));
     // decoder2: z2 -> x4
-    CVA_TRY(run_convT<T>(h->z[1], h->dec2_t[0], S0, B, gh, gw, st));
-    CVA_TRY(run_conv3<T>(S0, s11, nullptr, 0, h->dec2_c[0], S1, 0, B, 2 * gh, 2 * gw, st));
-    CVA_TRY(run_convT<T>(S1, h->dec2_t[1], S0, B, 2 * gh, 2 * gw, st));
-    CVA_TRY(run_conv3<T>(S0, 256, nullptr, 0, h->dec2_c[1], h->skip[2], 0, B, 4 * gh, 4 * gw, st));
+    CVA_TRY(run_deconv_block<T>(h->z[1], h->dec2_t[0], h->dec2_c[0], h->dec2_k[0], S0, S1, B, gh, gw, st));
+    CVA_TRY(run_deconv_block<T>(S1, h->dec2_t[1], h->dec2_c[1], h->dec2_k[1], S0, h->skip[2], B, 2 * gh, 2 * gw, st));
     // decoder3: z3 -> x2
-    CVA_TRY(run_convT<T>(h->z[2], h->dec3_t[0], S0, B, gh, gw, st));
-    CVA_TRY(run_conv3<T>(S0, bott, nullptr, 0, h->dec3_c[0], h->skip[3], 0, B, 2 * gh, 2 * gw, st));
+    CVA_TRY(run_deconv_block<T>(h->z[2], h->dec3_t[0], h->dec3_c[0], h->dec3_k[0], S0, h->skip[3], B, gh, gw, st));
 
     // ---- three upsampling branches (F10), concat order [skip, upsampled] (cellvit.py:236-242) ----
     for (int br = 0; br < 3; ++br) {
@@ -802,12 +919,12 @@ extern "C" int cv_finalize(cv_handle* h) {
     // 8 on the fp32 parity path (implicit GEMM, 16-byte pieces)
     CVA_TRY(pack_conv_block(h, "decoder0.0", 3, 32, &h->dec0[0], is_f32(h->cfg.compute_dtype) ? 8 : 32));
     CVA_TRY(pack_conv_block(h, "decoder0.1", 32, 64, &h->dec0[1]));
-    CVA_TRY(pack_deconv_block(h, "decoder1.0", D, s11, &h->dec1_t[0], &h->dec1_c[0]));
-    CVA_TRY(pack_deconv_block(h, "decoder1.1", s11, s12, &h->dec1_t[1], &h->dec1_c[1]));
-    CVA_TRY(pack_deconv_block(h, "decoder1.2", s12, 128, &h->dec1_t[2], &h->dec1_c[2]));
-    CVA_TRY(pack_deconv_block(h, "decoder2.0", D, s11, &h->dec2_t[0], &h->dec2_c[0]));
-    CVA_TRY(pack_deconv_block(h, "decoder2.1", s11, 256, &h->dec2_t[1], &h->dec2_c[1]));
-    CVA_TRY(pack_deconv_block(h, "decoder3.0", D, bott, &h->dec3_t[0], &h->dec3_c[0]));
+    CVA_TRY(pack_deconv_block(h, "decoder1.0", D, s11, &h->dec1_t[0], &h->dec1_c[0], &h->dec1_k[0]));
+    CVA_TRY(pack_deconv_block(h, "decoder1.1", s11, s12, &h->dec1_t[1], &h->dec1_c[1], &h->dec1_k[1]));
+    CVA_TRY(pack_deconv_block(h, "decoder1.2", s12, 128, &h->dec1_t[2], &h->dec1_c[2], &h->dec1_k[2]));
+    CVA_TRY(pack_deconv_block(h, "decoder2.0", D, s11, &h->dec2_t[0], &h->dec2_c[0], &h->dec2_k[0]));
+    CVA_TRY(pack_deconv_block(h, "decoder2.1", s11, 256, &h->dec2_t[1], &h->dec2_c[1], &h->dec2_k[1]));
+    CVA_TRY(pack_deconv_block(h, "decoder3.0", D, bott, &h->dec3_t[0], &h->dec3_c[0], &h->dec3_k[0]));
     const int nb = 2 + (c.regression_loss ? 2 : 0);
     CVA_TRY(pack_branch(h, "nuclei_binary_map_decoder", nb, &h->branch[0]));
     CVA_TRY(pack_branch(h, "hv_map_decoder", 2, &h->branch[1]));
@@ -1130,6 +1247,39 @@ extern "C" int cv_op_convT2x2(int dtype, const void* src, const void* Wk, const 
     ConvTW w; w.W = const_cast<void*>(Wk); w.bias4 = const_cast<float*>(bias4); w.Cin = Cin; w.Cout = Cout; w.ldw = Cin;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == CV_DTYPE_F16 ? run_convT<half_t>(src, w, out, B, H, W, st) : run_convT<float>(src, w, out, B, H, W, st);
+}
+
+extern "C" int cv_op_deconv_block(const float* wt, const float* bt, const float* w3, const float* b3, const float* bn_weight,
+                                  const float* bn_bias, const float* bn_mean, const float* bn_var, const void* src, void* out, int B,
+                                  int H, int W, int Cin, int Cout, void* stream) {
+    if (!wt || !bt || !w3 || !b3 || !bn_weight || !bn_bias || !bn_mean || !bn_var || !src || !out) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+    std::unique_ptr<cv_handle> h(new cv_handle());
+    h->cfg.compute_dtype = CV_DTYPE_F16;
+    auto put = [&](const char* key, const float* ptr, std::vector<int64_t> shape) {
+        HostTensor t; t.shape = std::move(shape); t.data.assign(ptr, ptr + t.numel());
+        h->raw[key] = std::move(t);
+    };
+    put("blk.block.0.weight", wt, {Cin, Cout, 2, 2}); put("blk.block.0.bias", bt, {Cout});
+    put("blk.block.1.weight", w3, {Cout, Cout, 3, 3}); put("blk.block.1.bias", b3, {Cout});
+    put("blk.block.2.weight", bn_weight, {Cout}); put("blk.block.2.bias", bn_bias, {Cout});
+    put("blk.block.2.running_mean", bn_mean, {Cout}); put("blk.block.2.running_var", bn_var, {Cout});
+    DeconvCompW k;
+    int rc = pack_deconv_comp(h.get(), "blk", Cin, Cout, &k);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (rc == CV_OK) {
+        if (!k.W) { cva_set_error("cv_op_deconv_block: Cout %% 256 == 0 and Cin %% 64 == 0 required"); rc = CV_ERR_UNSUPPORTED; }
+        else {
+            GemmParams p{};
+            p.M = B * H * W; p.N = 4 * Cout; p.K = 4 * Cin; p.A = src; p.W = k.W; p.ldw = p.K; p.H = H; p.Wd = W; p.C1 = Cin;
+            p.bias = k.bias4; p.comp_bias = k.btab; p.act = ACT_RELU; p.out_mode = OUT_CONVT; p.out = out;
+            const int r = launch_gemm8_deconv(p, st);
+            if (r == -1) { cva_set_error("cv_op_deconv_block: geometry outside the composed kernel (power-of-two sides, H*W >= 256)"); rc = CV_ERR_UNSUPPORTED; }
+            else if (r) { cva_set_error("composed deconv block launch failed (%d)", r); rc = CV_ERR_HIP; }
+            else if (hipStreamSynchronize(st) != hipSuccess) rc = CV_ERR_HIP;      // the composed weights are freed below
+        }
+    }
+    free_pool(h->allocs);
+    return rc;
 }
 
 extern "C" int cv_op_attention(int dtype, const void* x, const void* Wqkv, const float* bqkv, const float* tab_h,

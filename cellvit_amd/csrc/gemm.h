@@ -47,6 +47,10 @@ struct GemmParams {
     int H, Wd, C1, C2;
     int conv_kmajor;                 // filter K order: 0 = (tap, channel) as packed by pack_conv3, 1 = (64-channel chunk, tap, channel)
     int conv_wshift, conv_cshift;    // implicit 3x3 convolution on the 8-phase kernel: log2(W), log2((C1 + C2) / 64) (set by launch_gemm8_conv3)
+    // launch_gemm8_deconv (ConvTranspose2d k2 s2 followed by Conv2d 3x3 as ONE contraction over the low-resolution input, see gemm8.hip):
+    // bias of the output pixels on the image border, [9][N/4] indexed (row case * 3 + column case), case 0 = first, 1 = interior,
+    // 2 = last row / column of the 2H x 2W output; `bias` holds the interior case replicated per output parity ([N]).
+    const float* comp_bias;
     // ---- epilogue ----
     const float* bias;      // [N] or null
     int act;
@@ -100,6 +104,12 @@ void* gemm_zero_page();
 // sides); GemmParams as for A_CONV3.  Returns -1 if the layer does not fit.
 bool gemm8_conv3_supported(const GemmParams& p);
 int launch_gemm8_conv3(const GemmParams& p, hipStream_t stream);
+
+// gemm8.hip: ConvTranspose2d(k2, s2) -> Conv2d(3x3, pad 1) (-> ReLU) composed into one contraction over the INPUT pixels: M = B*H*W,
+// N = 4*Cout (n = (py*2 + px)*Cout + co, the output parity), K = 4*C1 (the 2x2 input pixels an output parity sees), W packed
+// [N][(64-channel chunk, ty-py, tx-px, channel)], OUT_CONVT scatter.  Cout a multiple of 256.  Returns -1 if the layer does not fit.
+bool gemm8_deconv_supported(const GemmParams& p);
+int launch_gemm8_deconv(const GemmParams& p, hipStream_t stream);
 
 // conv.hip: halo-tiled direct 3x3 convolution (fp16); GemmParams as for A_CONV3.  Returns -1 if the layer does not fit.
 int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream);

@@ -123,7 +123,8 @@ template <int OMODE, int TRANS, int ABL, int F8, int CV3>
 __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     static_assert(!F8 || (TRANS == 1 && ABL == 0), "the fp8 variant exists for the direct (transposed) epilogues only");
-    static_assert(!CV3 || (OMODE == OUT_LINEAR && TRANS == 1 && !F8), "implicit 3x3 convolution: fp16, direct linear epilogue");
+    static_assert(!CV3 || ((OMODE == OUT_LINEAR || OMODE == OUT_CONVT) && TRANS == 1 && !F8), "implicit 3x3 convolution: fp16, direct epilogues");
+    constexpr bool COMP = CV3 && OMODE == OUT_CONVT;    // ConvTranspose2d k2 s2 o Conv2d 3x3 composed (see launch_gemm8_deconv)
     constexpr int ESZ = F8 ? 1 : 2;                 // bytes per operand element; a tile row is 128 bytes either way
     constexpr int KTE = 128 / ESZ;                  // K elements per tile
 
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     // top-left tap of the tile's first pixel so that every tap offset is non-negative.
     unsigned cmask[2] = {0u, 0u};
     unsigned long long cbase1 = 0, cbase2 = 0;
+    int comp_tap0 = 0;              // COMP: 3x3-tap index of the tile's output parity's top-left input pixel, py*3 + px
     // F8: this wave's 256-byte share of the tile's scale block pair.  Waves 0-3 fetch the A-side block (scales of the
     // operand that sits in the "A" LDS tile), waves 4-7 the W-side block; block (row tile, K tile) is 1 KiB.
     const unsigned char* Sb = nullptr;
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             const long origin = ((long)m0 - p.Wd - 1) * p.C1 * 2;          // may lie before the tensor: only masked lanes would touch it
             cbase1 = (unsigned long long)(reinterpret_cast<const unsigned char*>(p.A) + origin);
             cbase2 = p.A2 ? (unsigned long long)(reinterpret_cast<const unsigned char*>(p.A2) + origin) : cbase1;
+            if (COMP) { const int par = n0 / (p.N >> 2); comp_tap0 = (par >> 1) * 3 + (par & 1); }
             Ab = nullptr;
             Wb = reinterpret_cast<const unsigned char*>(p.W) + (long)n0 * p.ldw * 2;
             return;
@@ -244,7 +247,11 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     auto stage_a_conv = [&](int buf, int kt) {
         const int kidx = kstart + kt * kstep;
         int tap, ch;
-        if (p.conv_kmajor) {          // K order (64-channel chunk, tap): the nine taps of a chunk re-read the same L2 lines back to back
+        if (COMP) {                   // K order (64-channel chunk, 2x2 input pixel): output parity (py, px) sees input pixels (y + py - 1 + s, x + px - 1 + t)
+            const int t4 = kidx & 3;
+            tap = __builtin_amdgcn_readfirstlane(comp_tap0 + (t4 >> 1) * 3 + (t4 & 1));
+            ch = (kidx >> 2) * G8_BK;
+        } else if (p.conv_kmajor) {          // K order (64-channel chunk, tap): the nine taps of a chunk re-read the same L2 lines back to back
             const int chunk = (kidx * 7282) >> 16;        // kidx / 9, exact for kidx < 4096
             tap = __builtin_amdgcn_readfirstlane(kidx - chunk * 9);
             ch = chunk * G8_BK;
@@ -580,6 +587,29 @@ int launch_gemm8_conv3(const GemmParams& p_in, hipStream_t stream) {
     p.conv_wshift = ilog2_exact(p.Wd);
     p.conv_cshift = ilog2_exact((p.C1 + p.C2) / G8_BK);
     return launch8<OUT_LINEAR, 1, 0, 0, 1>(p, stream);
+}
+
+// ConvTranspose2d(k2, s2) followed by Conv2d(3x3, pad 1): output pixel (2y + py, 2x + px) depends on the 2 x 2 input pixels
+// (y + py - 1 + s, x + px - 1 + t), s, t in {0, 1}, through weights composed on the host (cellvit_abi.hip, pack_deconv_comp) — one
+// contraction of K = 4 * Cin per output parity over the LOW-resolution pixels instead of K = Cin (transposed convolution) plus
+// K = 9 * Cout at four times the pixels, and the up-sampled intermediate never exists.  The A tile of K step (chunk, s, t) is the
+// 3x3-convolution tap (py + s, px + t) of the same machinery (stage_a_conv); a 256-column tile lies inside one parity.
+bool gemm8_deconv_supported(const GemmParams& p) {
+    if (p.out_mode != OUT_CONVT || p.out_f32 || p.res || p.head_W || !p.A || p.A2 || p.C2 || !p.W || !p.out || !p.bias || !p.comp_bias) return false;
+    if (p.N % 4 || (p.N / 4) % G8_BN || p.M % G8_BM || p.C1 % G8_BK || p.C1 < G8_BK) return false;
+    if (ilog2_exact(p.Wd) < 0 || ilog2_exact((long)p.H * p.Wd) < 8) return false;
+    if (p.K != 4 * p.C1 || p.ldw != p.K || ((size_t)p.A & 15) || ((size_t)p.W & 15) || ((size_t)p.out & 15) || ((size_t)p.comp_bias & 15)) return false;
+    if ((258L + 2L * p.Wd) * p.C1 * 2 >= (1L << 30) || 256L * p.ldw * 2 >= (1L << 31)) return false;
+    return true;
+}
+
+int launch_gemm8_deconv(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    if (!gemm8_deconv_supported(p)) return -1;
+    p.dbg = 0; p.epi_vec = 1; p.a_rpi = 0; p.o_rpi = 0; p.conv_kmajor = 1;
+    p.conv_wshift = ilog2_exact(p.Wd);
+    p.conv_cshift = 0;
+    return launch8<OUT_CONVT, 1, 0, 0, 1>(p, stream);
 }
 
 bool gemm8_f8_supported(const GemmParams& p) {

@@ -185,12 +185,39 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
             const int y = r2 / p.Wd, x = r2 - y * p.Wd;
             half_t* o = reinterpret_cast<half_t*>(p.out) +
                         (((long)b * 2 * p.H + 2 * y + (dd >> 1)) * (2 * p.Wd) + 2 * x + (dd & 1)) * cout + co;
+            if (p.comp_bias) {
+                // composed ConvTranspose2d o Conv2d 3x3: the 3x3 taps that fall outside the 2H x 2W image contribute neither their
+                // products (the input pixel's tap is masked in the A tile) nor their share of the transposed convolution's bias —
+                // border pixels take their bias from the per-case table instead of the staged interior one
+                const int Y = 2 * y + (dd >> 1), X = 2 * x + (dd & 1);
+                const int rc = Y == 0 ? 0 : (Y == 2 * p.H - 1 ? 2 : 1), cc = X == 0 ? 0 : (X == 2 * p.Wd - 1 ? 2 : 1);
+                if (rc != 1 || cc != 1) {
+                    const float* tb_ = p.comp_bias + (long)(rc * 3 + cc) * cout + co;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                half8_t w;
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(tb_ + q * 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
-                __builtin_nontemporal_store(w, reinterpret_cast<half8_t*>(o + q * 8));
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = acc[i][q][r] + t4[r];
+                            v[q * 4 + r] = p.act == ACT_RELU ? fmaxf(a, 0.f) : a;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {          // consumed by the next decoder stage: ordinary stores
+                    half8_t w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
+                    *reinterpret_cast<half8_t*>(o + q * 8) = w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    half8_t w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
+                    __builtin_nontemporal_store(w, reinterpret_cast<half8_t*>(o + q * 8));
+                }
             }
         } else {   // OUT_QKV, q or k columns
             int s_ = tb, pos = tt;
