@@ -76,7 +76,7 @@ SYMBOLS = {
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cv_op_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "cv_op_deconv_block": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_void_p]),
+    "cv_op_deconv_block": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 7 + [C.c_void_p]),
 }
 
 SYMBOLS.update({

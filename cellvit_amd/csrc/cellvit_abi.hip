@@ -91,7 +91,9 @@ struct ConvTW { void* W = nullptr; float* bias4 = nullptr; int Cin = 0, Cout = 0
 // Deconv2DBlock (ConvTranspose2d k2 s2 -> Conv2d 3x3 -> BatchNorm -> ReLU, models/segmentation/cell_segmentation/utils.py:46-86) composed into ONE contraction over
 // the block's INPUT pixels (fp16 engines, Cout % 256 == 0; gemm8.hip launch_gemm8_deconv): W [4*Cout][(64-ch chunk, 2x2 input pixel, ch)],
 // bias4 = interior bias per output parity, btab = the nine border cases.
-struct DeconvCompW { void* W = nullptr; float* bias4 = nullptr; float* btab = nullptr; int Cin = 0, Cout = 0; };
+// With Cs > 0 the 3x3 convolution runs on the concat [skip (Cs channels) || up-sampled] (cellvit.py:236-242, 255-304): the skip half's taps
+// follow the composed part as K columns [(64-ch chunk, tap, ch)], the same for every output parity.
+struct DeconvCompW { void* W = nullptr; float* bias4 = nullptr; float* btab = nullptr; int Cin = 0, Cout = 0, Cs = 0; };
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct HeadW { float* W = nullptr; float* b = nullptr; int n_out = 0; };
 struct BlockW {
@@ -103,6 +105,7 @@ struct BlockW {
 };
 struct BranchW {
     ConvTW up4; ConvW d3[3]; ConvTW up3; ConvW d2[2]; ConvTW up2; ConvW d1[2]; ConvTW up1; ConvW d0[2]; HeadW head;
+    DeconvCompW k3, k2;       // up4 -> d3[0] and up3 -> d2[0] composed (fp16 engines, Cout % 256 == 0)
 };
 
 struct Geometry {
@@ -357,31 +360,39 @@ int pack_convT(cv_handle* h, const std::string& key, int Cin, int Cout, ConvTW* 
 // The 36 products [Cout, Cup] x [Cup, Cz] run as fp32 GEMMs of the parity engine on the device (12 GMAC for 1280 -> 512: seconds on
 // the host), are read back, re-ordered to the kernel's K order and rounded ONCE to fp16.  Bias: b3' + sum over the taps INSIDE the
 // image of W3'[.,.,ky,kx] . bt — nine (row case, column case) tables; the interior one is the staged bias of every column tile.
-int pack_deconv_comp(cv_handle* h, const std::string& p, int Cin, int Cout, DeconvCompW* out) {
-    if (is_f32(h->cfg.compute_dtype) || Cout % 256 || Cin % 64) return CV_OK;       // not a shape the composed kernel takes
-    static const int use = cva_env_int("CVA_DECONV_COMP", 1);                        // ablation builds: 0 = the two-launch form (A/B)
-    if (!use) return CV_OK;
-    const int Cup = Cout;
-    const HostTensor* wt = find(h, p + ".block.0.weight", {Cin, Cup, 2, 2}); CVA_NEED(wt);
-    const HostTensor* bt = find(h, p + ".block.0.bias", {Cup}); CVA_NEED(bt);
-    const HostTensor* w3 = find(h, p + ".block.1.weight", {Cout, Cup, 3, 3}); CVA_NEED(w3);
-    const HostTensor* b3 = find(h, p + ".block.1.bias", {Cout}); CVA_NEED(b3);
-    const HostTensor* g = find(h, p + ".block.2.weight", {Cout}); CVA_NEED(g);
-    const HostTensor* be = find(h, p + ".block.2.bias", {Cout}); CVA_NEED(be);
-    const HostTensor* mu = find(h, p + ".block.2.running_mean", {Cout}); CVA_NEED(mu);
-    const HostTensor* var = find(h, p + ".block.2.running_var", {Cout}); CVA_NEED(var);
-    // folded 3x3 filters per tap [9][Cout][Cup], transposed-convolution taps [4][Cin][Cup] (both K = Cup contiguous), bias tables
-    std::vector<float> w3f((size_t)9 * Cout * Cup), wtt((size_t)4 * Cin * Cup);
+// convT_key: the ConvTranspose2d [Cin, Cup, 2, 2]; conv_key / bn_key: the Conv2d [Cout, Cs + Cup, 3, 3] + BatchNorm2d that consume
+// [skip (Cs, may be 0) || up-sampled (Cup)].
+int pack_deconv_comp(cv_handle* h, const std::string& convT_key, const std::string& conv_key, const std::string& bn_key, int Cin, int Cup,
+                     int Cs, int Cout, DeconvCompW* out) {
+    if (is_f32(h->cfg.compute_dtype) || Cout % 256 || Cin % 64 || Cs % 64 || ((4 * Cin + 9 * Cs) / 64) % 2) return CV_OK;   // not a shape the composed kernel takes
+    static const int use = cva_env_int("CVA_DECONV_COMP", 3);                        // ablation builds (A/B): bit 0 = Deconv2DBlocks, bit 1 = branch stages
+    if (!(use & (Cs ? 2 : 1))) return CV_OK;
+    const std::string& p = convT_key;
+    const int Ccat = Cs + Cup;
+    const HostTensor* wt = find(h, convT_key + ".weight", {Cin, Cup, 2, 2}); CVA_NEED(wt);
+    const HostTensor* bt = find(h, convT_key + ".bias", {Cup}); CVA_NEED(bt);
+    const HostTensor* w3 = find(h, conv_key + ".weight", {Cout, Ccat, 3, 3}); CVA_NEED(w3);
+    const HostTensor* b3 = find(h, conv_key + ".bias", {Cout}); CVA_NEED(b3);
+    const HostTensor* g = find(h, bn_key + ".weight", {Cout}); CVA_NEED(g);
+    const HostTensor* be = find(h, bn_key + ".bias", {Cout}); CVA_NEED(be);
+    const HostTensor* mu = find(h, bn_key + ".running_mean", {Cout}); CVA_NEED(mu);
+    const HostTensor* var = find(h, bn_key + ".running_var", {Cout}); CVA_NEED(var);
+    // folded 3x3 filters of the up-sampled half per tap [9][Cout][Cup], transposed-convolution taps [4][Cin][Cup] (both K = Cup
+    // contiguous), bias tables; folded filters of the skip half in the kernel's K order [Cout][(chunk, tap, ch)]
+    std::vector<float> w3f((size_t)9 * Cout * Cup), wtt((size_t)4 * Cin * Cup), wsk((size_t)Cout * 9 * Cs);
     std::vector<double> b3f(Cout), tb((size_t)9 * Cout, 0.0);
     for (int co = 0; co < Cout; ++co) {
         const double scale = (double)g->data[co] / std::sqrt((double)var->data[co] + BN_EPS);
         b3f[co] = (double)b3->data[co] * scale + ((double)be->data[co] - (double)mu->data[co] * scale);
         for (int cu = 0; cu < Cup; ++cu)
             for (int t = 0; t < 9; ++t) {
-                const double w = (double)w3->data[((size_t)co * Cup + cu) * 9 + t] * scale;
+                const double w = (double)w3->data[((size_t)co * Ccat + Cs + cu) * 9 + t] * scale;
                 w3f[((size_t)t * Cout + co) * Cup + cu] = (float)w;
                 tb[(size_t)t * Cout + co] += w * (double)bt->data[cu];
             }
+        for (int cs = 0; cs < Cs; ++cs)
+            for (int t = 0; t < 9; ++t)
+                wsk[(size_t)co * 9 * Cs + ((size_t)(cs / 64) * 9 + t) * 64 + (cs & 63)] = (float)((double)w3->data[((size_t)co * Ccat + cs) * 9 + t] * scale);
     }
     for (int cz = 0; cz < Cin; ++cz)
         for (int cu = 0; cu < Cup; ++cu)
@@ -430,15 +441,17 @@ int pack_deconv_comp(cv_handle* h, const std::string& p, int Cin, int Cout, Deco
     }
     cleanup();
     if (rc != CV_OK) { cva_set_error("composing '%s' on the device failed", p.c_str()); return rc; }
-    const int K = 4 * Cin, chunks = Cin / 64;
+    const int K = 4 * Cin + 9 * Cs, chunks = Cin / 64;
     std::vector<float> wk((size_t)4 * Cout * K);
     for (int par = 0; par < 4; ++par)
-        for (int co = 0; co < Cout; ++co)
+        for (int co = 0; co < Cout; ++co) {
+            float* row = &wk[((size_t)par * Cout + co) * K];
             for (int ch = 0; ch < chunks; ++ch)
                 for (int t4 = 0; t4 < 4; ++t4)
-                    memcpy(&wk[((size_t)par * Cout + co) * K + ((size_t)ch * 4 + t4) * 64],
-                           &hc[((size_t)(par * 4 + t4) * Cout + co) * Cin + (size_t)ch * 64], 64 * sizeof(float));
-    out->Cin = Cin; out->Cout = Cout;
+                    memcpy(row + ((size_t)ch * 4 + t4) * 64, &hc[((size_t)(par * 4 + t4) * Cout + co) * Cin + (size_t)ch * 64], 64 * sizeof(float));
+            if (Cs) memcpy(row + (size_t)4 * Cin, &wsk[(size_t)co * 9 * Cs], (size_t)9 * Cs * sizeof(float));
+        }
+    out->Cin = Cin; out->Cout = Cout; out->Cs = Cs;
     CVA_TRY(upload_matrix(h, wk.data(), 4 * Cout, K, K, &out->W));
     CVA_TRY(upload_f32(h, b4.data(), b4.size(), &out->bias4));
     CVA_TRY(upload_f32(h, btab.data(), btab.size(), &out->btab));
@@ -451,7 +464,7 @@ int pack_conv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvW
 int pack_deconv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvTW* t, ConvW* c, DeconvCompW* k) {
     CVA_TRY(pack_convT(h, p + ".block.0", Cin, Cout, t));
     CVA_TRY(pack_conv3(h, p + ".block.1", p + ".block.2", Cout, Cout, Cout, true, 1, c));
-    return pack_deconv_comp(h, p, Cin, Cout, k);
+    return pack_deconv_comp(h, p + ".block.0", p + ".block.1", p + ".block.2", Cin, Cout, 0, Cout, k);
 }
 
 void skip_dims(const cv_config& c, int* s11, int* s12, int* bott) {   // cellvit.py:106-113
@@ -474,6 +487,8 @@ int pack_branch(cv_handle* h, const std::string& p, int n_out, BranchW* b) {
     CVA_TRY(pack_convT(h, p + ".decoder1_upsampler.2", 128, 64, &b->up1));
     CVA_TRY(pack_conv_block(h, p + ".decoder0_header.0", 128, 64, &b->d0[0]));
     CVA_TRY(pack_conv_block(h, p + ".decoder0_header.1", 64, 64, &b->d0[1]));
+    CVA_TRY(pack_deconv_comp(h, p + ".bottleneck_upsampler", p + ".decoder3_upsampler.0.block.0", p + ".decoder3_upsampler.0.block.1", D, bott, bott, bott, &b->k3));
+    CVA_TRY(pack_deconv_comp(h, p + ".decoder3_upsampler.3", p + ".decoder2_upsampler.0.block.0", p + ".decoder2_upsampler.0.block.1", bott, 256, 256, 256, &b->k2));
     const HostTensor* w = find(h, p + ".decoder0_header.2.weight", {n_out, 64, 1, 1}); CVA_NEED(w);
     const HostTensor* bb = find(h, p + ".decoder0_header.2.bias", {n_out}); CVA_NEED(bb);
     b->head.n_out = n_out;
@@ -577,25 +592,26 @@ int run_convT(const void* src, const ConvTW& w, void* out, int B, int Hs, int Ws
     return CV_OK;
 }
 
-// Deconv2DBlock: the composed single launch where the block and the geometry fit it (fp16 engines), else ConvTranspose2d into `tmp`
-// and the 3x3 convolution from there.
+// ConvTranspose2d k2 s2 of `src` followed by the 3x3 convolution block over [skip (may be null) || up-sampled]: the composed single
+// launch where the layer and the geometry fit it (fp16 engines), else ConvTranspose2d into `tmp` and the convolution from there.
 template <typename T>
-int run_deconv_block(const void* src, const ConvTW& t, const ConvW& c, const DeconvCompW& k, void* tmp, void* out, int B, int Hs, int Ws,
-                     hipStream_t st) {
+int run_deconv_block(const void* src, const void* skip, const ConvTW& t, const ConvW& c, const DeconvCompW& k, void* tmp, void* out, int B,
+                     int Hs, int Ws, hipStream_t st) {
     if (sizeof(T) == 2 && k.W) {
         GemmParams p{};
-        p.M = B * Hs * Ws; p.N = 4 * k.Cout; p.K = 4 * k.Cin; p.A = src; p.W = k.W; p.ldw = p.K;
-        p.H = Hs; p.Wd = Ws; p.C1 = k.Cin;
+        p.M = B * Hs * Ws; p.N = 4 * k.Cout; p.K = 4 * k.Cin + 9 * k.Cs; p.A = src; p.W = k.W; p.ldw = p.K;
+        p.H = Hs; p.Wd = Ws; p.C1 = k.Cin; p.A2 = k.Cs ? skip : nullptr; p.C2 = k.Cs;
         p.bias = k.bias4; p.comp_bias = k.btab; p.act = ACT_RELU; p.out_mode = OUT_CONVT; p.out = out;
         int rc;
         {
-            ProfScope ps(KC_CONV3, 2.0 * p.M * (double)p.N * p.K, st);      // executed FLOPs (the two-launch form: 2*M*4*Cout*(Cin + 9*Cout))
+            ProfScope ps(KC_CONV3, 2.0 * p.M * (double)p.N * p.K, st);      // executed FLOPs (the two-launch form: 2*M*4*(Cup*Cin + Cout*9*(Cs + Cup)))
             rc = launch_gemm8_deconv(p, st);
         }
         if (rc == 0) return CV_OK;
         if (rc != -1) { cva_set_error("composed deconv block launch failed (%d)", rc); return CV_ERR_HIP; }
     }
     CVA_TRY(run_convT<T>(src, t, tmp, B, Hs, Ws, st));
+    if (skip) return run_conv3<T>(skip, c.Ctot - t.Cout, tmp, t.Cout, c, out, 0, B, 2 * Hs, 2 * Ws, st);
     return run_conv3<T>(tmp, c.Ctot, nullptr, 0, c, out, 0, B, 2 * Hs, 2 * Ws, st);
 }
 
@@ -754,26 +770,24 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
     CVA_TRY(run_conv3<T>(h->img8, h->dec0[0].Ctot, nullptr, 0, h->dec0[0], S0, 0, B, H, W, st));
     CVA_TRY(run_conv3<T>(S0, 32, nullptr, 0, h->dec0[1], h->skip[0], 0, B, H, W, st));
     // decoder1: z1 -> x8
-    CVA_TRY(run_deconv_block<T>(h->z[0], h->dec1_t[0], h->dec1_c[0], h->dec1_k[0], S0, S1, B, gh, gw, st));
-    CVA_TRY(run_deconv_block<T>(S1, h->dec1_t[1], h->dec1_c[1], h->dec1_k[1], S0, S2, B, 2 * gh, 2 * gw, st));
-    CVA_TRY(run_deconv_block<T>(S2, h->dec1_t[2], h->dec1_c[2], h->dec1_k[2], S0, h->skip[1], B, 4 * gh, 4 * gw, st));
+    CVA_TRY(run_deconv_block<T>(h->z[0], nullptr, h->dec1_t[0], h->dec1_c[0], h->dec1_k[0], S0, S1, B, gh, gw, st));
+    CVA_TRY(run_deconv_block<T>(S1, nullptr, h->dec1_t[1], h->dec1_c[1], h->dec1_k[1], S0, S2, B, 2 * gh, 2 * gw, st));
+    CVA_TRY(run_deconv_block<T>(S2, nullptr, h->dec1_t[2], h->dec1_c[2], h->dec1_k[2], S0, h->skip[1], B, 4 * gh, 4 * gw, st));
     // decoder2: z2 -> x4
-    CVA_TRY(run_deconv_block<T>(h->z[1], h->dec2_t[0], h->dec2_c[0], h->dec2_k[0], S0, S1, B, gh, gw, st));
-    CVA_TRY(run_deconv_block<T>(S1, h->dec2_t[1], h->dec2_c[1], h->dec2_k[1], S0, h->skip[2], B, 2 * gh, 2 * gw, st));
+    CVA_TRY(run_deconv_block<T>(h->z[1], nullptr, h->dec2_t[0], h->dec2_c[0], h->dec2_k[0], S0, S1, B, gh, gw, st));
+    CVA_TRY(run_deconv_block<T>(S1, nullptr, h->dec2_t[1], h->dec2_c[1], h->dec2_k[1], S0, h->skip[2], B, 2 * gh, 2 * gw, st));
     // decoder3: z3 -> x2
-    CVA_TRY(run_deconv_block<T>(h->z[2], h->dec3_t[0], h->dec3_c[0], h->dec3_k[0], S0, h->skip[3], B, gh, gw, st));
+    CVA_TRY(run_deconv_block<T>(h->z[2], nullptr, h->dec3_t[0], h->dec3_c[0], h->dec3_k[0], S0, h->skip[3], B, gh, gw, st));
 
     // ---- three upsampling branches (F10), concat order [skip, upsampled] (cellvit.py:236-242) ----
     for (int br = 0; br < 3; ++br) {
         const BranchW& b = h->branch[br];
-        CVA_TRY(run_convT<T>(h->z[3], b.up4, S0, B, gh, gw, st));
-        CVA_TRY(run_conv3<T>(h->skip[3], bott, S0, bott, b.d3[0], S1, 0, B, 2 * gh, 2 * gw, st));
+        CVA_TRY(run_deconv_block<T>(h->z[3], h->skip[3], b.up4, b.d3[0], b.k3, S0, S1, B, gh, gw, st));
         CVA_TRY(run_conv3<T>(S1, bott, nullptr, 0, b.d3[1], S2, 0, B, 2 * gh, 2 * gw, st));
         CVA_TRY(run_conv3<T>(S2, bott, nullptr, 0, b.d3[2], S1, 0, B, 2 * gh, 2 * gw, st));
-        CVA_TRY(run_convT<T>(S1, b.up3, S0, B, 2 * gh, 2 * gw, st));
-        CVA_TRY(run_conv3<T>(h->skip[2], 256, S0, 256, b.d2[0], S1, 0, B, 4 * gh, 4 * gw, st));
-        CVA_TRY(run_conv3<T>(S1, 256, nullptr, 0, b.d2[1], S2, 0, B, 4 * gh, 4 * gw, st));
-        CVA_TRY(run_convT<T>(S2, b.up2, S0, B, 4 * gh, 4 * gw, st));
+        CVA_TRY(run_deconv_block<T>(S1, h->skip[2], b.up3, b.d2[0], b.k2, S0, S2, B, 2 * gh, 2 * gw, st));
+        CVA_TRY(run_conv3<T>(S2, 256, nullptr, 0, b.d2[1], S1, 0, B, 4 * gh, 4 * gw, st));
+        CVA_TRY(run_convT<T>(S1, b.up2, S0, B, 4 * gh, 4 * gw, st));
         CVA_TRY(run_conv3<T>(h->skip[1], 128, S0, 128, b.d1[0], S1, 0, B, 8 * gh, 8 * gw, st));
         CVA_TRY(run_conv3<T>(S1, 128, nullptr, 0, b.d1[1], S2, 0, B, 8 * gh, 8 * gw, st));
         CVA_TRY(run_convT<T>(S2, b.up1, S0, B, 8 * gh, 8 * gw, st));
@@ -1250,27 +1264,30 @@ extern "C" int cv_op_convT2x2(int dtype, const void* src, const void* Wk, const 
 }
 
 extern "C" int cv_op_deconv_block(const float* wt, const float* bt, const float* w3, const float* b3, const float* bn_weight,
-                                  const float* bn_bias, const float* bn_mean, const float* bn_var, const void* src, void* out, int B,
-                                  int H, int W, int Cin, int Cout, void* stream) {
-    if (!wt || !bt || !w3 || !b3 || !bn_weight || !bn_bias || !bn_mean || !bn_var || !src || !out) { cva_set_error("bad argument"); return CV_ERR_INVALID; }
+                                  const float* bn_bias, const float* bn_mean, const float* bn_var, const void* src, const void* skip,
+                                  void* out, int B, int H, int W, int Cin, int Cup, int Cs, int Cout, void* stream) {
+    if (!wt || !bt || !w3 || !b3 || !bn_weight || !bn_bias || !bn_mean || !bn_var || !src || !out || (Cs > 0) != (skip != nullptr) || Cs < 0) {
+        cva_set_error("bad argument"); return CV_ERR_INVALID;
+    }
     std::unique_ptr<cv_handle> h(new cv_handle());
     h->cfg.compute_dtype = CV_DTYPE_F16;
     auto put = [&](const char* key, const float* ptr, std::vector<int64_t> shape) {
         HostTensor t; t.shape = std::move(shape); t.data.assign(ptr, ptr + t.numel());
         h->raw[key] = std::move(t);
     };
-    put("blk.block.0.weight", wt, {Cin, Cout, 2, 2}); put("blk.block.0.bias", bt, {Cout});
-    put("blk.block.1.weight", w3, {Cout, Cout, 3, 3}); put("blk.block.1.bias", b3, {Cout});
-    put("blk.block.2.weight", bn_weight, {Cout}); put("blk.block.2.bias", bn_bias, {Cout});
-    put("blk.block.2.running_mean", bn_mean, {Cout}); put("blk.block.2.running_var", bn_var, {Cout});
+    put("up.weight", wt, {Cin, Cup, 2, 2}); put("up.bias", bt, {Cup});
+    put("conv.weight", w3, {Cout, Cs + Cup, 3, 3}); put("conv.bias", b3, {Cout});
+    put("bn.weight", bn_weight, {Cout}); put("bn.bias", bn_bias, {Cout});
+    put("bn.running_mean", bn_mean, {Cout}); put("bn.running_var", bn_var, {Cout});
     DeconvCompW k;
-    int rc = pack_deconv_comp(h.get(), "blk", Cin, Cout, &k);
+    int rc = pack_deconv_comp(h.get(), "up", "conv", "bn", Cin, Cup, Cs, Cout, &k);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (rc == CV_OK) {
-        if (!k.W) { cva_set_error("cv_op_deconv_block: Cout %% 256 == 0 and Cin %% 64 == 0 required"); rc = CV_ERR_UNSUPPORTED; }
+        if (!k.W) { cva_set_error("cv_op_deconv_block: Cout %% 256 == 0, Cin %% 64 == 0, Cs %% 64 == 0 and an even number of 64-wide K steps required"); rc = CV_ERR_UNSUPPORTED; }
         else {
             GemmParams p{};
-            p.M = B * H * W; p.N = 4 * Cout; p.K = 4 * Cin; p.A = src; p.W = k.W; p.ldw = p.K; p.H = H; p.Wd = W; p.C1 = Cin;
+            p.M = B * H * W; p.N = 4 * Cout; p.K = 4 * Cin + 9 * Cs; p.A = src; p.A2 = skip; p.C2 = Cs; p.W = k.W; p.ldw = p.K;
+            p.H = H; p.Wd = W; p.C1 = Cin;
             p.bias = k.bias4; p.comp_bias = k.btab; p.act = ACT_RELU; p.out_mode = OUT_CONVT; p.out = out;
             const int r = launch_gemm8_deconv(p, st);
             if (r == -1) { cva_set_error("cv_op_deconv_block: geometry outside the composed kernel (power-of-two sides, H*W >= 256)"); rc = CV_ERR_UNSUPPORTED; }

@@ -152,7 +152,10 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     // top-left tap of the tile's first pixel so that every tap offset is non-negative.
     unsigned cmask[2] = {0u, 0u};
     unsigned long long cbase1 = 0, cbase2 = 0;
-    int comp_tap0 = 0;              // COMP: 3x3-tap index of the tile's output parity's top-left input pixel, py*3 + px
+    // COMP: output parity of the tile's columns, the tile's first pixel inside its image, and per lane row four border flags
+    // (bit 0: y == 0, 1: y == H-1, 2: x == 0, 3: x == W-1; row i in bits 4i..4i+3) from which every tap's validity follows
+    int comp_py = 0, comp_px = 0, comp_pim = 0;
+    unsigned eflags = 0u;
     // F8: this wave's 256-byte share of the tile's scale block pair.  Waves 0-3 fetch the A-side block (scales of the
     // operand that sits in the "A" LDS tile), waves 4-7 the W-side block; block (row tile, K tile) is 1 KiB.
     const unsigned char* Sb = nullptr;
@@ -169,6 +172,32 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         kstart = rev ? nk - 1 : 0; kstep = rev ? -1 : 1;
         // v columns of the fused qkv projection: exchange the operands (see epilogue8_vt); block-uniform
         swap = OMODE == OUT_QKV && TRANS == 1 && (n0 + p.n_off) >= 2 * p.D;
+        if (COMP) {
+            const int pim = m0 & (p.H * p.Wd - 1);
+            const int par = n0 / (p.N >> 2);
+            comp_py = par >> 1; comp_px = par & 1; comp_pim = pim;
+            eflags = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wave * 32 + i * 8 + lrow;
+                const int lp = lpc ^ ((row >> 1) & 7);
+                const int prow = (row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3);
+                const int pp = pim + row, y = pp >> p.conv_wshift, x = pp & (p.Wd - 1);
+                eflags |= ((y == 0 ? 1u : 0u) | (y == p.H - 1 ? 2u : 0u) | (x == 0 ? 4u : 0u) | (x == p.Wd - 1 ? 8u : 0u)) << (4 * i);
+                a_voff[i] = (unsigned)(row * p.C1 * 2) + lp * 16;
+                w_voff[i] = (unsigned)((long)prow * p.ldw * 2) + lp * 16;
+            }
+            // input pixels: base at the top-left 3x3 tap of the tile's first pixel.  Second source (the skip connection at the
+            // OUTPUT resolution, 2H x 2W): input pixel m = (b*H + y)*W + x maps to output pixel index 4*m - 2*x of parity (0, 0);
+            // base at that pixel's top-left tap for the tile's first pixel.
+            const long origin = ((long)m0 - p.Wd - 1) * p.C1 * 2;
+            cbase1 = (unsigned long long)(reinterpret_cast<const unsigned char*>(p.A) + origin);
+            const long origin2 = (4L * m0 - 2L * (pim & (p.Wd - 1)) - 2L * p.Wd - 1) * p.C2 * 2;
+            cbase2 = p.A2 ? (unsigned long long)(reinterpret_cast<const unsigned char*>(p.A2) + origin2) : cbase1;
+            Ab = nullptr;
+            Wb = reinterpret_cast<const unsigned char*>(p.W) + (long)n0 * p.ldw * 2;
+            return;
+        }
         if (CV3) {
             const int pim = m0 & (p.H * p.Wd - 1);          // first pixel of the tile inside its image (H*W a power of two)
             cmask[0] = cmask[1] = 0u;
@@ -188,7 +217,6 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             const long origin = ((long)m0 - p.Wd - 1) * p.C1 * 2;          // may lie before the tensor: only masked lanes would touch it
             cbase1 = (unsigned long long)(reinterpret_cast<const unsigned char*>(p.A) + origin);
             cbase2 = p.A2 ? (unsigned long long)(reinterpret_cast<const unsigned char*>(p.A2) + origin) : cbase1;
-            if (COMP) { const int par = n0 / (p.N >> 2); comp_tap0 = (par >> 1) * 3 + (par & 1); }
             Ab = nullptr;
             Wb = reinterpret_cast<const unsigned char*>(p.W) + (long)n0 * p.ldw * 2;
             return;
@@ -246,12 +274,49 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
                  "s"(soff), "s"(ldsaddr) : "memory")
     auto stage_a_conv = [&](int buf, int kt) {
         const int kidx = kstart + kt * kstep;
+        if (COMP) {
+            // K steps [0, C1/16): the composed part, K order (64-channel chunk, 2x2 input pixel) — output parity (py, px) sees input
+            // pixels (y + py - 1 + s, x + px - 1 + t) = 3x3 tap (py + s, px + t) of the input image.  K steps beyond: the 3x3 taps of
+            // the second source at the output resolution, K order (64-channel chunk, tap); output pixel (2y + py, 2x + px).
+            const int nkc = p.C1 >> 4;
+            unsigned sm, soff; unsigned long long b; bool first;
+            if (kidx < nkc) {
+                const int t4 = kidx & 3, ty = comp_py + (t4 >> 1), tx = comp_px + (t4 & 1);
+                sm = (ty == 0 ? 1u : 0u) | (ty == 2 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == 2 ? 8u : 0u);
+                soff = (unsigned)(((ty * p.Wd + tx) * p.C1 + (kidx >> 2) * G8_BK) * 2);
+                b = cbase1; first = true;
+            } else {
+                const int k2 = kidx - nkc, chunk = (k2 * 7282) >> 16, tap = k2 - chunk * 9;      // k2 / 9, exact for k2 < 4096
+                const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+                sm = (ky == 0 && comp_py == 0 ? 1u : 0u) | (ky == 2 && comp_py == 1 ? 2u : 0u) |
+                     (kx == 0 && comp_px == 0 ? 4u : 0u) | (kx == 2 && comp_px == 1 ? 8u : 0u);
+                soff = (unsigned)((((comp_py + ky) * 2 * p.Wd + comp_px + kx) * p.C2 + chunk * G8_BK) * 2);
+                b = cbase2; first = false;
+            }
+            sm = __builtin_amdgcn_readfirstlane(sm); soff = __builtin_amdgcn_readfirstlane(soff);
+            i32x4_t d;
+            d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+            d[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));
+            d[2] = 0x40000000;
+            d[3] = 0x00020000;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G8_TILE + wave * 4096);
+            const int x0 = comp_pim & (p.Wd - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned vo = a_voff[i];
+                if (!first) {         // block-uniform: the lane's pixel at the output resolution, relative to the tile's first
+                    int row = wave * 32 + i * 8 + lrow;
+                    asm volatile("" : "+v"(row));      // recomputed per K step (a few VALU ops): hoisted, the four offsets cost registers this kernel does not have
+                    const int x = (comp_pim + row) & (p.Wd - 1);
+                    vo = (unsigned)((4 * row - 2 * (x - x0)) * p.C2 * 2) + ((lpc ^ ((row >> 1) & 7)) << 4);
+                }
+                if ((eflags >> (4 * i)) & sm) vo = 0x80000000u;        // tap outside the image: the DMA writes zeros
+                G8_BDMA(vo, d, soff, dst + i * 1024);
+            }
+            return;
+        }
         int tap, ch;
-        if (COMP) {                   // K order (64-channel chunk, 2x2 input pixel): output parity (py, px) sees input pixels (y + py - 1 + s, x + px - 1 + t)
-            const int t4 = kidx & 3;
-            tap = __builtin_amdgcn_readfirstlane(comp_tap0 + (t4 >> 1) * 3 + (t4 & 1));
-            ch = (kidx >> 2) * G8_BK;
-        } else if (p.conv_kmajor) {          // K order (64-channel chunk, tap): the nine taps of a chunk re-read the same L2 lines back to back
+        if (p.conv_kmajor) {          // K order (64-channel chunk, tap): the nine taps of a chunk re-read the same L2 lines back to back
             const int chunk = (kidx * 7282) >> 16;        // kidx / 9, exact for kidx < 4096
             tap = __builtin_amdgcn_readfirstlane(kidx - chunk * 9);
             ch = chunk * G8_BK;
@@ -594,12 +659,18 @@ int launch_gemm8_conv3(const GemmParams& p_in, hipStream_t stream) {
 // contraction of K = 4 * Cin per output parity over the LOW-resolution pixels instead of K = Cin (transposed convolution) plus
 // K = 9 * Cout at four times the pixels, and the up-sampled intermediate never exists.  The A tile of K step (chunk, s, t) is the
 // 3x3-convolution tap (py + s, px + t) of the same machinery (stage_a_conv); a 256-column tile lies inside one parity.
+// With a second source A2 (NHWC [B, 2H, 2W, C2]: the skip connection the up-sampled map is concatenated with, cellvit.py:236-242) the
+// same accumulators also take the 3x3 convolution of that source — K grows by 9 * C2 steps whose A tiles are the tap-shifted
+// OUTPUT-resolution pixels (2y + py, 2x + px) of the tile's input pixels (a stride-2 gather: per-lane offsets, as before).
 bool gemm8_deconv_supported(const GemmParams& p) {
-    if (p.out_mode != OUT_CONVT || p.out_f32 || p.res || p.head_W || !p.A || p.A2 || p.C2 || !p.W || !p.out || !p.bias || !p.comp_bias) return false;
+    if (p.out_mode != OUT_CONVT || p.out_f32 || p.res || p.head_W || !p.A || !p.W || !p.out || !p.bias || !p.comp_bias) return false;
+    if ((p.A2 != nullptr) != (p.C2 > 0) || p.C2 % G8_BK) return false;
     if (p.N % 4 || (p.N / 4) % G8_BN || p.M % G8_BM || p.C1 % G8_BK || p.C1 < G8_BK) return false;
     if (ilog2_exact(p.Wd) < 0 || ilog2_exact((long)p.H * p.Wd) < 8) return false;
-    if (p.K != 4 * p.C1 || p.ldw != p.K || ((size_t)p.A & 15) || ((size_t)p.W & 15) || ((size_t)p.out & 15) || ((size_t)p.comp_bias & 15)) return false;
-    if ((258L + 2L * p.Wd) * p.C1 * 2 >= (1L << 30) || 256L * p.ldw * 2 >= (1L << 31)) return false;
+    const int K = 4 * p.C1 + 9 * p.C2;
+    if (p.K != K || p.ldw != K || (K / G8_BK) % 2 || 9 * p.C2 / G8_BK >= 4096) return false;
+    if (((size_t)p.A & 15) || ((size_t)p.A2 & 15) || ((size_t)p.W & 15) || ((size_t)p.out & 15) || ((size_t)p.comp_bias & 15)) return false;
+    if ((258L + 2L * p.Wd) * p.C1 * 2 >= (1L << 30) || (1026L + 4L * p.Wd) * p.C2 * 2 >= (1L << 30) || 256L * p.ldw * 2 >= (1L << 31)) return false;
     return true;
 }
 

@@ -149,14 +149,16 @@ int cv_op_conv3x3(int dtype, const void* src1, int C1, const void* src2, int C2,
 /* NHWC ConvTranspose2d k2 s2: Wk [4*Cout, Cin] (n = (dy*2+dx)*Cout + co), bias4 fp32 [4*Cout].         */
 int cv_op_convT2x2(int dtype, const void* src, const void* Wk, const float* bias4, void* out,
                    int B, int H, int W, int Cin, int Cout, void* stream);
-/* Deconv2DBlock (models/segmentation/cell_segmentation/utils.py:46-86: ConvTranspose2d k2 s2 -> Conv2d 3x3 pad 1 ->
- * BatchNorm2d (eval) -> ReLU; dropout is identity in eval) as ONE launch on the fp16 engine: the two linear maps are composed into a
- * contraction over the block's input pixels.  Weights are HOST fp32 arrays in the reference's layouts (wt [Cin, Cout, 2, 2],
- * w3 [Cout, Cout, 3, 3]); src fp16 NHWC [B, H, W, Cin], out fp16 NHWC [B, 2H, 2W, Cout] on the device.  Cout % 256 == 0, Cin % 64 == 0,
- * power-of-two H, W with H*W >= 256, else CV_ERR_UNSUPPORTED.  Synchronises the stream (the composed weights are temporary).           */
+/* ConvTranspose2d k2 s2 -> Conv2d 3x3 pad 1 -> BatchNorm2d (eval) -> ReLU as ONE launch on the fp16 engine: the two linear maps are
+ * composed into a contraction over the INPUT pixels.  Cs == 0: Deconv2DBlock (models/segmentation/cell_segmentation/
+ * utils.py:46-86; dropout is identity in eval).  Cs > 0: the decoder stages of cellvit.py:255-304, where the convolution runs on
+ * torch.cat([skip, up-sampled], dim=1) (cellvit.py:236-242) — `skip` fp16 NHWC [B, 2H, 2W, Cs] on the device.
+ * Weights are HOST fp32 arrays in the reference's layouts (wt [Cin, Cup, 2, 2], w3 [Cout, Cs + Cup, 3, 3]); src fp16 NHWC [B, H, W, Cin],
+ * out fp16 NHWC [B, 2H, 2W, Cout] on the device.  Cout % 256 == 0, Cin % 64 == 0, Cs % 64 == 0, (4 Cin + 9 Cs) / 64 even, power-of-two
+ * H, W with H*W >= 256, else CV_ERR_UNSUPPORTED.  Synchronises the stream (the composed weights are temporary).                          */
 int cv_op_deconv_block(const float* wt, const float* bt, const float* w3, const float* b3, const float* bn_weight,
-                       const float* bn_bias, const float* bn_mean, const float* bn_var, const void* src, void* out, int B,
-                       int H, int W, int Cin, int Cout, void* stream);
+                       const float* bn_bias, const float* bn_mean, const float* bn_var, const void* src, const void* skip,
+                       void* out, int B, int H, int W, int Cin, int Cup, int Cs, int Cout, void* stream);
 /* One attention layer on token rows x[B*ntok, D] (already normalised): qkv GEMM + scatter, optional
  * window partition (win > 0, zero-padded tokens) and decomposed rel-pos (tab_h/tab_w != NULL).
  * out: `dtype` [B*ntok, D] = softmax(...)·v re-assembled in token order (before the output proj).     */

@@ -160,38 +160,42 @@ def test_convT2x2(dtype, B, H, W_, Cin, Cout):
     assert err < (1e-5 if dtype == F32 else 2e-3), err
 
 
-@pytest.mark.parametrize("B,H,W_,Cin,Cout", [(2, 16, 16, 128, 256), (1, 32, 16, 64, 256), (1, 4, 64, 192, 512), (3, 16, 16, 320, 256)])
-def test_deconv_block_composed(B, H, W_, Cin, Cout):
-    """Deconv2DBlock (models/segmentation/cell_segmentation/utils.py:46-86: ConvTranspose2d k2 s2 -> Conv2d 3x3 -> BatchNorm2d -> ReLU) as one
-    composed launch against the torch modules in fp32 on the same (fp16-rounded) input: interior and all border cases of the 2H x 2W
-    output, several images per launch, K steps of an odd chunk count."""
+@pytest.mark.parametrize("B,H,W_,Cin,Cs,Cout", [(2, 16, 16, 128, 0, 256), (1, 32, 16, 64, 0, 256), (1, 4, 64, 192, 0, 512), (3, 16, 16, 320, 0, 256),
+                                                   (2, 16, 16, 128, 256, 256), (1, 8, 32, 64, 128, 256), (1, 2, 256, 192, 128, 512), (3, 16, 16, 128, 384, 256)])
+def test_deconv_block_composed(B, H, W_, Cin, Cs, Cout):
+    """ConvTranspose2d k2 s2 -> Conv2d 3x3 -> BatchNorm2d -> ReLU as one composed launch against the torch modules in fp32 on the same
+    (fp16-rounded) inputs.  Cs == 0: Deconv2DBlock (models/segmentation/cell_segmentation/utils.py:46-86); Cs > 0: the convolution runs on
+    torch.cat([skip, up-sampled], dim=1) (cellvit.py:236-242, 255-304).  Interior and all border cases of the 2H x 2W output, several
+    images per launch, odd chunk counts, rows wider than a tile."""
     L, lib = _lib()
     g = torch.Generator().manual_seed(11)
+    Cup = Cout
     x = torch.randn(B, H, W_, Cin, generator=g)
-    wt = torch.randn(Cin, Cout, 2, 2, generator=g) / math.sqrt(Cin)
-    bt = torch.randn(Cout, generator=g) * 0.3
-    w3 = torch.randn(Cout, Cout, 3, 3, generator=g) / math.sqrt(9 * Cout)
+    skip = torch.randn(B, 2 * H, 2 * W_, Cs, generator=g) if Cs else None
+    wt = torch.randn(Cin, Cup, 2, 2, generator=g) / math.sqrt(Cin)
+    bt = torch.randn(Cup, generator=g) * 0.3
+    w3 = torch.randn(Cout, Cs + Cup, 3, 3, generator=g) / math.sqrt(9 * (Cs + Cup))
     b3 = torch.randn(Cout, generator=g) * 0.1
     bn_w = torch.rand(Cout, generator=g) + 0.5
     bn_b = torch.randn(Cout, generator=g) * 0.1
     bn_m = torch.randn(Cout, generator=g) * 0.1
     bn_v = torch.rand(Cout, generator=g) + 0.5
     xd = _dev(x, F16)
+    sd = _dev(skip, F16) if Cs else None
     out = torch.full((B, 2 * H, 2 * W_, Cout), float("nan"), device="cuda", dtype=torch.float16)
-    hp = lambda t: C.c_void_p(t.contiguous().data_ptr())  # noqa: E731  (host fp32 arrays)
-    host = [t.contiguous() for t in (wt, bt, w3, b3, bn_w, bn_b, bn_m, bn_v)]
-    L.check(lib.cv_op_deconv_block(*[hp(t) for t in host], _p(xd), _p(out), B, H, W_, Cin, Cout, None))
+    host = [t.contiguous() for t in (wt, bt, w3, b3, bn_w, bn_b, bn_m, bn_v)]       # host fp32 arrays
+    L.check(lib.cv_op_deconv_block(*[C.c_void_p(t.data_ptr()) for t in host], _p(xd), _p(sd), _p(out), B, H, W_, Cin, Cup, Cs, Cout, None))
     torch.cuda.synchronize()
-    xin = xd.float().cpu().permute(0, 3, 1, 2)
-    up = F.conv_transpose2d(xin, wt, bt, stride=2)
-    y = F.conv2d(up, w3, b3, padding=1)
+    up = F.conv_transpose2d(xd.float().cpu().permute(0, 3, 1, 2), wt, bt, stride=2)
+    cat = torch.cat([sd.float().cpu().permute(0, 3, 1, 2), up], dim=1) if Cs else up
+    y = F.conv2d(cat, w3, b3, padding=1)
     y = F.batch_norm(y, bn_m, bn_v, bn_w, bn_b, training=False, eps=1e-5)
     ref = F.relu(y).permute(0, 2, 3, 1)
     got = out.float().cpu()
     assert torch.isfinite(got).all()
     err = _rel_err(got, ref)
     assert err < 2e-3, err
-    # the border rows / columns on their own (a wrong bias case would hide in the global norm)
+    # the border rows / columns on their own (a wrong bias case or tap mask would hide in the global norm)
     for sl in (got[:, 0] - ref[:, 0], got[:, -1] - ref[:, -1], got[:, :, 0] - ref[:, :, 0], got[:, :, -1] - ref[:, :, -1]):
         assert float(sl.abs().max()) < 2e-2 * float(ref.abs().max()), float(sl.abs().max())
 
