@@ -44,6 +44,10 @@ struct PadKVParams {        // window mode: keys/values of zero-padded tokens ar
 template <typename T> int launch_attention(const AttnParams& p, hipStream_t stream);
 // v2 (attention2.hip): fused rel-pos; returns -1 when the geometry is not covered (caller uses v1 + launch_relpos)
 template <typename T> int launch_attention2(const AttnParams& p, hipStream_t stream);
+// attention3.hip: fp16 global attention (no windows, >= 256 keys, hd 64 / 80; rel-pos only in the key-tile-aligned form KW == 64):
+// one 8-wave workgroup per CU, MFMA and softmax phases of the two wave groups in counter-phase, LDS-DMA staging.  -1 when not covered.
+// Measured equal to attention2 (the two pipes of a SIMD do not overlap across waves): ablation builds only, production returns -1.
+int launch_attention3(const AttnParams& p, hipStream_t stream);
 // attention_win.hip: single-pass kernel for <= 208 keys (SAM windows), fp16 only; -1 when not covered
 int launch_attention_win(const AttnParams& p, hipStream_t stream);
 template <typename T> int launch_relpos(const RelPosParams& p, hipStream_t stream);

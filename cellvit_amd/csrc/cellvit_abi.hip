@@ -651,13 +651,14 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
     a.S = S; a.heads = heads; a.L = L; a.Lp = Lp; a.hd = hd; a.D = D; a.nk = L; a.KH = KH; a.KW = KW;
     a.scale = 1.0f / std::sqrt((float)hd);
     a.ntok = ntok; a.win = window ? ws : 0; a.gw = gw; a.gh = gh; a.nwx = nwx; a.nwy = nwy;
-    static const int attn_variant = cva_env_int("CVA_ATTN", 3);   // 3: window kernel + v2, 2: v2 only, 1: v1
+    static const int attn_variant = cva_env_int("CVA_ATTN", 3);   // 3: window kernel + v2, 5: window kernel + v3 (attention3.hip, measured not faster) + v2, 2: v2 only, 1: v1
     if (attn_variant != 1) {
         a.tab_h = tab_h; a.tab_w = tab_w;
         ProfScope ps(KC_ATTN, 4.0 * (double)B * P * (window ? L : ntok) * hd * heads + (window ? 0.0 : 4.0 * B * has_cls * (double)ntok * hd * heads), st);
         int rc2 = -1;
         a.win_prep = ((size_t)S * heads * L * KH * 4 >= 32768) ? (void*)relh : nullptr;   // the v1 bias scratch doubles as the window kernel's prep area
         if (sizeof(T) == 2 && attn_variant != 2) rc2 = launch_attention_win(a, st);     // short key sequences (windows)
+        if (rc2 == -1 && sizeof(T) == 2 && attn_variant == 5) rc2 = launch_attention3(a, st);   // experiment (ablation builds): 8-wave counter-phase kernel
         if (rc2 == -1) rc2 = launch_attention2<T>(a, st);
         if (rc2 == 0) return CV_OK;
         if (rc2 != -1) { cva_set_error("attention2 launch failed (%d)", rc2); return CV_ERR_HIP; }
