@@ -81,7 +81,9 @@ struct HostTensor {
     size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
 };
 
-struct LinearW { void* W = nullptr; float* bias = nullptr; int N = 0, K = 0, ldw = 0;
+// Np: rows of W / entries of bias as packed (fp16 engines pad N to the 8-phase kernel's 256-column tile when the layer is otherwise its
+// shape: zero rows, zero bias; the padded columns are dropped in the epilogue — gemm.h n_valid).  Np == N: not padded.
+struct LinearW { void* W = nullptr; float* bias = nullptr; int N = 0, K = 0, ldw = 0, Np = 0;
                  void* W8 = nullptr; void* S8 = nullptr; };   // fp8 engine: e4m3 bytes [N, K] + E8M0 scale blocks (gemm.h)
 struct ConvW {
     void* W = nullptr; float* bias = nullptr; int Cout = 0, Ctot = 0, K = 0, ldw = 0; int relu = 1; int Cin_real = 0;
@@ -275,11 +277,22 @@ int pack_linear(cv_handle* h, const std::string& p, int N, int K, bool bias, Lin
     const HostTensor* w = find(h, p + ".weight", {N, K});
     CVA_NEED(w);
     out->N = N; out->K = K; out->ldw = round_up(K, bk_of(h->cfg.compute_dtype));
-    CVA_TRY(upload_matrix(h, w->data.data(), N, K, out->ldw, &out->W));
+    // ViT-S (N = 384 / 1152): pad to the 256-column tile of the 8-phase kernel (K must already be its shape: a multiple of 128)
+    const bool pad = !is_f32(h->cfg.compute_dtype) && N >= 256 && N % 256 != 0 && N % 16 == 0 && K % 128 == 0 && K >= 128;
+    out->Np = pad ? round_up(N, 256) : N;
+    if (pad) {
+        std::vector<float> wp((size_t)out->Np * K, 0.f);
+        memcpy(wp.data(), w->data.data(), (size_t)N * K * sizeof(float));
+        CVA_TRY(upload_matrix(h, wp.data(), out->Np, K, out->ldw, &out->W));
+    } else {
+        CVA_TRY(upload_matrix(h, w->data.data(), N, K, out->ldw, &out->W));
+    }
     if (bias) {
         const HostTensor* b = find(h, p + ".bias", {N});
         CVA_NEED(b);
-        CVA_TRY(upload_f32(h, b->data.data(), N, &out->bias));
+        std::vector<float> bp((size_t)out->Np, 0.f);
+        memcpy(bp.data(), b->data.data(), (size_t)N * sizeof(float));
+        CVA_TRY(upload_f32(h, bp.data(), out->Np, &out->bias));
     }
     return CV_OK;
 }
@@ -511,11 +524,15 @@ void free_pool(std::vector<void*>& pool) {
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
+// Mp > M: the operand and output buffers hold Mp rows (a multiple of 256, workspace of cv_set_geometry) and the launch covers them all
+// — rows >= M are computed on whatever the buffers hold and never read back.
 template <typename T>
 int run_linear(const void* A, int lda, const LinearW& w, const float* res, int ldres, int res_mod, void* out,
-               int ldc, int out_f32, int M, int act, hipStream_t st, int o_rpi = 0, int o_extra = 0, int o_off = 0) {
+               int ldc, int out_f32, int M, int act, hipStream_t st, int o_rpi = 0, int o_extra = 0, int o_off = 0, int Mp = 0) {
     GemmParams p{};
     p.M = M; p.N = w.N; p.K = w.K; p.A = A; p.W = w.W; p.lda = lda; p.ldw = w.ldw;
+    if (sizeof(T) == 2 && w.Np > w.N && (M % 256 == 0 || Mp > M)) { p.N = w.Np; p.n_valid = w.N; }     // padded columns (pack_linear)
+    if (sizeof(T) == 2 && Mp > M && p.N % 256 == 0) { p.M = Mp; p.m_valid = M; }
     p.bias = w.bias; p.act = act; p.res = res; p.ldres = ldres; p.res_mod = res_mod;
     p.out_mode = OUT_LINEAR; p.out_f32 = out_f32; p.out = out; p.ldc = ldc;
     p.o_rpi = o_rpi; p.o_extra = o_extra; p.o_off = o_off;
@@ -622,13 +639,17 @@ template <typename T>
 int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, const float* tab_w, bool window,
                         void* Q, void* K, void* Vt, float* relh, float* relw, void* attn_out, int B, int gh, int gw,
                         int has_cls, int heads, int D, int ws, hipStream_t st, bool prepadded = false,
-                        const void* xn_sca = nullptr, const void* xn_scw = nullptr) {
+                        const void* xn_sca = nullptr, const void* xn_scw = nullptr, int Mp = 0) {
     const int hd = D / heads, P = gh * gw, ntok = P + has_cls;
     const int nwy = window ? (gh + ws - 1) / ws : 0, nwx = window ? (gw + ws - 1) / ws : 0;
     const int L = window ? ws * ws : ntok, Lp = round_up(L, 64);
     const int S = window ? B * nwy * nwx : B;
     GemmParams g{};
     g.M = B * ntok; g.N = 3 * D; g.K = D; g.A = xn; g.W = qkv.W; g.lda = D; g.ldw = qkv.ldw;
+    if (sizeof(T) == 2 && !xn_sca && (g.M % 256 == 0 || Mp > g.M) && qkv.Np % 256 == 0) {       // padded to the 8-phase kernel's tile (ViT-S)
+        if (qkv.Np > g.N) { g.n_valid = g.N; g.N = qkv.Np; }
+        if (Mp > g.M) { g.m_valid = g.M; g.M = Mp; }
+    }
     g.bias = qkv.bias; g.act = ACT_NONE; g.out_mode = OUT_QKV;
     g.q_out = Q; g.k_out = K; g.vt_out = Vt;
     g.D = D; g.hd = hd; g.heads = heads; g.ntok = ntok; g.L = L; g.Lp = Lp;
@@ -638,7 +659,7 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
         ProfScope ps(KC_GEMM_MX8, 2.0 * g.M * (double)g.N * g.K, st);
         const int rc8 = launch_gemm8_f8(g, st);
         if (rc8) { cva_set_error("fp8 qkv gemm launch failed (%d)", rc8); return rc8 == (int)hipErrorInvalidValue ? CV_ERR_UNSUPPORTED : CV_ERR_HIP; }
-    } else { ProfScope ps(KC_GEMM_QKV, 2.0 * g.M * (double)g.N * g.K, st); CVA_LAUNCH(launch_gemm<T>(g, A_LINEAR, st)); }
+    } else { ProfScope ps(KC_GEMM_QKV, 2.0 * B * ntok * 3.0 * D * g.K, st); CVA_LAUNCH(launch_gemm<T>(g, A_LINEAR, st)); }
     if (!prepadded && window && (nwy * ws != gh || nwx * ws != gw)) {
         PadKVParams pk{};
         pk.K = K; pk.Vt = Vt; pk.qkv_bias = qkv.bias; pk.B = B; pk.heads = heads; pk.hd = hd; pk.D = D; pk.L = L;
@@ -695,6 +716,9 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
     int zi = 0;
     const bool fuse_add = sizeof(T) == 2 && !h->debug && !h->no_ln_add;   // proj's residual add fused into LayerNorm 2
     const bool f8 = sizeof(T) == 2 && c.compute_dtype == CV_DTYPE_F8;     // MX-fp8 qkv / fc1 / fc2 (BASELINE.json configs[4])
+    // fp16 engine, token rows not a multiple of the 8-phase kernel's tile (ViT: the cls token): the block GEMMs cover the padded rows too
+    static const int pad_rows = cva_env_int("CVA_GEMM_PAD", 1);            // ablation builds: 0 = exact extents (the 128 x 128 kernel), A/B
+    const int Mp = (sizeof(T) == 2 && !f8 && pad_rows && M % 256) ? (M + 255) / 256 * 256 : 0;
     for (int i = 0; i < c.depth; ++i) {
         const BlockW& b = h->blocks[i];
         if (f8) CVA_LAUNCH(launch_layernorm_mx8(h->resid, D, nullptr, b.n1.g, b.n1.b, h->xn8, h->xn_sca, h->xn_scw, M, D, LN_EPS, st));
@@ -703,15 +727,15 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
         const bool own_kv = window && b.Kw && b.Vtw;
         CVA_TRY(run_attention_layer<T>(f8 ? h->xn8 : h->xn, b.qkv, b.tab_h, b.tab_w, window, h->Q, own_kv ? b.Kw : h->K,
                                        own_kv ? b.Vtw : (window ? h->Vt_win : h->Vt_glob), h->relh, h->relw, h->attn_out, B, g.gh, g.gw,
-                                       g.has_cls, heads, D, c.window_size, st, own_kv, f8 ? h->xn_sca : nullptr, f8 ? h->xn_scw : nullptr));
+                                       g.has_cls, heads, D, c.window_size, st, own_kv, f8 ? h->xn_sca : nullptr, f8 ? h->xn_scw : nullptr, Mp));
         if (fuse_add) {
             // fp16 engine: proj writes its fp16 output (as the reference's autocast Linear does); the add into the fp32
             // residual stream rides with LayerNorm 2, which has to stream that row anyway (elementwise.hip)
-            CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, nullptr, 0, 0, h->xn, D, 0, M, ACT_NONE, st));
+            CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, nullptr, 0, 0, h->xn, D, 0, M, ACT_NONE, st, 0, 0, 0, Mp));
             if (f8) CVA_LAUNCH(launch_layernorm_mx8(h->resid, D, h->xn, b.n2.g, b.n2.b, h->xn8, h->xn_sca, nullptr, M, D, LN_EPS, st));
             else CVA_LAUNCH(launch_layernorm_add(h->resid, D, h->xn, b.n2.g, b.n2.b, h->xn, M, D, LN_EPS, st));
         } else {
-            CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st));
+            CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st, 0, 0, 0, Mp));
             if (f8) CVA_LAUNCH(launch_layernorm_mx8(h->resid, D, nullptr, b.n2.g, b.n2.b, h->xn8, h->xn_sca, nullptr, M, D, LN_EPS, st));
             else CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n2.g, b.n2.b, h->xn, 0, M, D, LN_EPS, st));
         }
@@ -720,10 +744,10 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
             CVA_TRY(run_linear_mx8(h->xn8, h->xn_sca, D, b.fc1, nullptr, 0, h->hidden8, hid, 0, OUT_MX8, h->hidden_sc, M, ACT_GELU, st));
             CVA_TRY(run_linear_mx8(h->hidden8, h->hidden_sc, hid, b.fc2, h->resid, D, h->resid, D, 1, OUT_LINEAR, nullptr, M, ACT_NONE, st));
         } else {
-            CVA_TRY(run_linear<T>(h->xn, D, b.fc1, nullptr, 0, 0, h->hidden, hid, 0, M, ACT_GELU, st));
+            CVA_TRY(run_linear<T>(h->xn, D, b.fc1, nullptr, 0, 0, h->hidden, hid, 0, M, ACT_GELU, st, 0, 0, 0, Mp));
             // (deferring the fc2 add into the next block's LayerNorm 1 the same way was measured neutral: K = 5120 hides more
             //  of the epilogue, and the add costs the LayerNorm what it saves the GEMM)
-            CVA_TRY(run_linear<T>(h->hidden, hid, b.fc2, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st));
+            CVA_TRY(run_linear<T>(h->hidden, hid, b.fc2, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st, 0, 0, 0, Mp));
         }
         if (h->debug)
             CVA_CHECK_HIP(hipMemcpyAsync(h->dbg_blocks + (size_t)i * g.B * ntok * D, h->resid, (size_t)M * D * 4,
@@ -988,8 +1012,11 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
         return dev_alloc(h->ws_allocs, p, bytes, zero);
     };
     CVA_TRY(A(&h->patchA, (size_t)B * g.P * 768 * es));
-    CVA_TRY(A((void**)&h->resid, M * D * 4));
-    CVA_TRY(A(&h->xn, M * D * es));
+    // token-row buffers hold a whole number of 256-row GEMM tiles (ViT: M = B * (P + 1)); the pad rows are zeroed once and only ever
+    // rewritten by padded launches (run_linear Mp)
+    const size_t Mr = (M + 255) / 256 * 256;
+    CVA_TRY(A((void**)&h->resid, Mr * D * 4, Mr != M));
+    CVA_TRY(A(&h->xn, Mr * D * es, Mr != M));
     const size_t nwin = (size_t)g.nwy * g.nwx;
     const size_t qk_elems = std::max((size_t)B * heads * g.Lg * hd, (size_t)B * nwin * heads * g.Lw * hd);
     CVA_TRY(A(&h->Q, qk_elems * es, true));
@@ -1019,7 +1046,7 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
         CVA_TRY(A((void**)&h->neck_f32a, M * c.neck_chans * 4));
         CVA_TRY(A((void**)&h->neck_f32b, M * c.neck_chans * 4));
     }
-    CVA_TRY(A(&h->attn_out, M * D * es));
+    CVA_TRY(A(&h->attn_out, Mr * D * es, Mr != M));
     if (dt == CV_DTYPE_F8) {
         if (M % 256 != 0) { cva_set_error("fp8 engine: batch * tokens (%zu) must be a multiple of 256", M); return CV_ERR_UNSUPPORTED; }
         const size_t hid8 = (size_t)D * c.mlp_ratio;
@@ -1030,7 +1057,7 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
         CVA_TRY(A(&h->hidden_sc, M * hid8 / 32, true));
         h->hidden = nullptr;
     } else {
-        CVA_TRY(A(&h->hidden, M * D * c.mlp_ratio * es));
+        CVA_TRY(A(&h->hidden, Mr * D * c.mlp_ratio * es, Mr != M));
     }
     for (int j = 0; j < 4; ++j) CVA_TRY(A(&h->z[j], (size_t)B * g.P * D * es));
     CVA_TRY(A(&h->img8, (size_t)B * H * W * h->dec0[0].Ctot * es));

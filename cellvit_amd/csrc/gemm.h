@@ -76,6 +76,10 @@ struct GemmParams {
     const void* a_scale_w;           // the same scales in the W-side layout (needed by the swapped V tiles of OUT_QKV), or null
     const void* w_scale;             // weight scales; tiles that run swapped (qkv rows >= 2D) are packed in the A-side layout
     void* out_scale;                 // OUT_MX8: scales of the fp8 output (A-side layout for a consumer GEMM with K = N)
+    // 8-phase kernel on shapes that are not multiples of its 256 x 256 tile (ViT-S: M = B * 4097 rows, N = 384 / 1152 columns): the caller
+    // pads — M and N are the padded extents (operand rows exist up to M; W / bias are zero padded to N), rows >= m_valid and columns
+    // >= n_valid are computed and dropped in the epilogue.  0 = no guard.  n_valid a multiple of 16; OUT_QKV: n_valid == 3 * D.
+    int m_valid, n_valid;
     int epi_vec;                     // 1: LDS-staged 16-byte epilogue stores (set by launch_gemm)
     int dbg;                         // experiment switches (CVA_GEMM_DBG): 1 no staging, 2 no LDS reads, 4 no L2 prefetch
 };

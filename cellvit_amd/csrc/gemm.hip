@@ -180,6 +180,10 @@ int launch_gemm(const GemmParams& p_in, int a_mode, hipStream_t stream) {
         const long t256 = (long)(p.M / 256) * (p.N / 256);
         if (t256 >= 192 && gemm8_supported(p, a_mode, sizeof(T))) return launch_gemm8(p, stream);   // >= 75 % of the 256 CUs
     }
+    // padded launch (gemm.h m_valid / n_valid) that the 8-phase kernel does not take after all: this kernel has edge tiles of its own,
+    // run the real extents
+    if (p.n_valid) { p.N = p.n_valid; p.n_valid = 0; }
+    if (p.m_valid) { p.M = p.m_valid; p.m_valid = 0; }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const dim3 g(tiles), b(NT);
     if (a_mode == A_CONV3) {

@@ -626,7 +626,10 @@ bool gemm8_supported(const GemmParams& p, int a_mode, size_t elem_size) {
     if (((size_t)p.A & 15) || ((size_t)p.W & 15) || (p.lda % 8) || (p.ldw % 8) || p.ldw < p.K) return false;
     // (32-bit lane offsets are relative to a tile's first row: 256 rows, plus the few rows an a_rpi remap can insert)
     if ((256L + (p.a_rpi > 0 ? (256L / p.a_rpi + 1) * p.a_extra : 0)) * p.lda * 2 >= (1L << 31) || 256L * p.ldw * 2 >= (1L << 31)) return false;
-    if (p.out_mode == OUT_QKV && (p.D % G8_BN || p.hd % 16 || p.N != 3 * p.D || p.n_off)) return false;
+    if (p.n_valid && (p.n_valid % 16 || p.n_valid > p.N || p.N - p.n_valid >= G8_BN || p.out_mode == OUT_CONVT)) return false;
+    if (p.m_valid && (p.m_valid > p.M || p.M - p.m_valid >= G8_BM)) return false;
+    // fused qkv projection: the v columns (operands exchanged, V^T epilogue) must start on a column tile
+    if (p.out_mode == OUT_QKV && ((2 * p.D) % G8_BN || p.hd % 16 || (p.n_valid ? p.n_valid : p.N) != 3 * p.D || p.n_off)) return false;
     return true;
 }
 

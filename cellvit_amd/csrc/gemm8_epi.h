@@ -69,6 +69,7 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
                                                  const int mrow0, const int ncol0, const int lane, const float* lut) {
     const int g = lane >> 4, li = lane & 15;
     const int n = ncol0 + g * 16;
+    if (p.n_valid && n >= p.n_valid) return;            // padded columns (no cross-lane operation below: OUT_MX8 never runs padded)
     half_t* qk = nullptr;
     long col_term = 0;
     if (OMODE == OUT_QKV) {
@@ -236,6 +237,7 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
                 while (tgx >= p.gw) { tgx -= p.gw; ++tgy; }
             }
             half_t* o = qk + ((long)s_ * p.heads * p.L + pos) * p.hd + col_term;
+            if (p.m_valid && m >= p.m_valid) continue;      // padded rows (the token walk above is already advanced)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 half8_t w;
@@ -260,7 +262,9 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
     const int mb = mcol0 + g * 16;                               // first of this lane's 16 tokens
     half_t* vt = reinterpret_cast<half_t*>(p.vt_out);
     const int b0 = mb / p.ntok, t0 = mb - b0 * p.ntok;
-    const bool fast = p.win == 0 && t0 + 15 < p.ntok && (t0 & 7) == 0;
+    const int mlim = p.m_valid ? p.m_valid : 0x7fffffff;        // padded token rows are dropped
+    if (mb >= mlim) return;
+    const bool fast = p.win == 0 && t0 + 15 < p.ntok && (t0 & 7) == 0 && mb + 15 < mlim;
     // Window layers whose grid width is a multiple of 16 (1024-px tiles: 64): the lane's 16 tokens lie in ONE grid row and
     // split into at most two runs that are contiguous in V^T — the rest of window wxA's row (lenA tokens from px = pxA) and
     // the start of the next window's row.  With even window size all lengths are even: dwords 0-3 go out as one 16-byte
@@ -283,6 +287,7 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
     // token -> offset inside one (s, h, d) row of V^T for the 16 tokens (8 pairs), walked incrementally (no divisions
     // per token; window index by float reciprocal, exact for coordinate * win < 2^21)
     long po0[8], po1[8]; bool pair_ok[8];
+    unsigned tok_ok = 0xffffu;                                   // bit 2u + w: token mb + 2u + w is a real row
     if (!fast && !wide) {
         const float inv_win = 1.0f / (float)(p.win > 0 ? p.win : 1);
         const bool fwin = p.win > 0 && p.gw <= 4096 && p.gh <= 4096 && p.win <= 256;
@@ -306,7 +311,9 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
                 else if (p.win > 0 && gx >= p.gw) { gx = 0; ++gy; }
             }
             po0[u] = o[0]; po1[u] = o[1];
-            pair_ok[u] = (o[1] == o[0] + 1) && ((o[0] & 1) == 0);
+            pair_ok[u] = (o[1] == o[0] + 1) && ((o[0] & 1) == 0) && mb + 2 * u + 1 < mlim;
+            if (mb + 2 * u >= mlim) tok_ok &= ~(1u << (2 * u));
+            if (mb + 2 * u + 1 >= mlim) tok_ok &= ~(2u << (2 * u));
         }
     }
     const int c0 = nrow0 + li + p.n_off - 2 * p.D;              // v column of fragment row 0; +16 per fragment row
@@ -317,6 +324,7 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
         const long rowoff = ((long)h * p.hd + d) * p.Lp;
         d += 16;
         while (d >= p.hd) { d -= p.hd; ++h; }
+        if (p.n_valid && c0 + 16 * i >= p.D) continue;           // padded v columns
         if (fast) {
             half_t* dst = vt + (long)b0 * p.heads * p.hd * p.Lp + rowoff + t0;
 #pragma unroll
@@ -368,8 +376,8 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
                     const half2_t w = {v0, v1};
                     *reinterpret_cast<half2_t*>(vt + po0[u] + rowoff) = w;
                 } else {
-                    vt[po0[u] + rowoff] = v0;
-                    vt[po1[u] + rowoff] = v1;
+                    if (tok_ok & (1u << (2 * u))) vt[po0[u] + rowoff] = v0;
+                    if (tok_ok & (2u << (2 * u))) vt[po1[u] + rowoff] = v1;
                 }
             }
         }

@@ -138,6 +138,32 @@ def test_forward_vit256_1024_fp32_crops_and_fp16_full_map():
     assert ag_t >= ARGMAX_TYPE and ag_b >= ARGMAX_BIN
 
 
+def test_forward_vit256_1024_batch_takes_the_padded_tile_route():
+    """A batch of 8 tiles puts CellViT-256's linear layers on the 256 x 256 kernel with PADDED extents (M = 8 * 4097 rows -> a
+    multiple of 256, N = 384 / 1152 columns -> 512 / 1280, padded rows / columns dropped in the epilogue); one tile alone runs the
+    exact-extent kernel.  Eight copies of the golden tile must reproduce the single-tile maps and each other (same fp16 arithmetic,
+    different accumulation tiling), and the extra rows must not leak into real ones: tissue logits and tokens too."""
+    cfg, sd, x, gold = load_case("vit256_1024")
+    m16 = _model(cfg, sd, "fp16")
+    one = m16(x.cuda(), retrieve_tokens=True)
+    torch.cuda.synchronize()
+    one = {k: v.float().clone() for k, v in one.items() if torch.is_tensor(v)}
+    xb = x.repeat(8, 1, 1, 1).contiguous().cuda()
+    many = m16(xb, retrieve_tokens=True)
+    torch.cuda.synchronize()
+    for k in ("tissue_types", "nuclei_binary_map", "hv_map", "nuclei_type_map", "tokens"):
+        v = many[k].float()
+        assert torch.isfinite(v).all(), k
+        tol = ATOL_F16 if k != "tokens" else 2e-3 * max(1.0, one[k].abs().max().item())      # tokens: relative (abs max ~ 10)
+        for i in range(1, 8):        # rows of a GEMM do not depend on their neighbours (only the K walk's direction alternates by tile)
+            assert (v[i] - v[0]).abs().max().item() < tol, (k, i, (v[i] - v[0]).abs().max().item())
+        d = (v[0] - one[k][0]).abs()
+        print(f"[vit256_1024 batch 8 vs 1] {k}: max abs {d.max().item():.3e} (tolerance {tol:.1e})")
+        assert d.max().item() < tol, (k, d.max().item())
+    ag = (many["nuclei_type_map"][0].argmax(0) == one["nuclei_type_map"][0].argmax(0)).float().mean().item()
+    assert ag >= ARGMAX_TYPE, ag
+
+
 def test_forward_errors():
     cfg, sd, x, _ = load_case("vit256_256")
     m = _model(cfg, sd, "fp32")
