@@ -239,3 +239,28 @@ def test_forward_fp8_error_statistics(name):
     for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
         assert s8[k][0] < 0.25 and s8[k][1] < 0.03, (k, s8[k])
     assert s8["nuclei_binary_map_argmax"] >= 0.97 and s8["nuclei_type_map_argmax"] >= 0.95, s8
+
+
+def test_samh_1024_fp8_instance_level_gate():
+    """Instance-level gate for the fp8 engine (SURVEY §8 row "HV/type logits": tolerance gates for fp16 / fp8 at the level the
+    product is consumed): the post-processed instance maps of the fp8 engine against those of the exact-fp32 engine on the full
+    1024^2 SAM-H tile — PQ of one against the other, as tests/test_gpu_forward.py does for fp16 (printed next to it)."""
+    from cellvit_amd.metrics import panoptic_quality, remap_label
+    cfg, sd, x, _ = load_case("samh_1024")
+    res = {}
+    m32 = _model(cfg, sd, "fp32")
+    b = m32(x.cuda())
+    ib, _ = m32.calculate_instance_map(b, 40)
+    ib = ib[0].numpy().astype(np.int32)
+    del m32, b
+    for dt in ("fp16", "fp8"):
+        m = _model(cfg, sd, dt)
+        a = m(x.cuda())
+        ia, _ = m.calculate_instance_map(a, 40)
+        ia = ia[0].numpy().astype(np.int32)
+        assert ia.max() > 0 and ib.max() > 0
+        (dq, sq, pq), _ = panoptic_quality(remap_label(ib), remap_label(ia))
+        res[dt] = (dq, sq, pq, int(ia.max()))
+        del m, a
+    print(f"\n[samh_1024] instance maps vs the fp32 engine ({int(ib.max())} instances): (DQ, SQ, PQ, instances) fp16 {res['fp16']}  fp8 {res['fp8']}")
+    assert res["fp8"][2] > 0.80, res
