@@ -22,6 +22,13 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
 
+# Per-file flags.  -fno-slp-vectorize: hipcc's SLP vectoriser packs adjacent fp32 multiplies / adds into v_pk_mul_f32 / v_pk_add_f32, and a
+# packed fp32 VALU instruction next to MFMAs (same wave or the SIMD's other wave) stalls the matrix pipe — measured
+# (tools/probes/probe_mfma_valu_overlap.hip, profiles/r03_probe_mfma_valu_overlap.txt): plain v_fma_f32 fillers hide under the MFMAs, the
+# packed form costs more than running the two streams one after the other.
+FILE_FLAGS = {}
+
+
 def _hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -51,10 +58,11 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
     flags = FLAGS + (["-DCVA_ABLATION"] if ablation else []) + extra
     flags = flags + ['-DCVA_BUILD_FLAGS_STR="' + " ".join(flags[1:]).replace('"', "'") + '"']
     stamp = os.path.join(OBJ, ".flags")          # (untracked: _obj*/ is git-ignored)
-    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+    stamp_text = " ".join(flags) + " | " + repr(sorted(FILE_FLAGS.items()))
+    if not os.path.exists(stamp) or open(stamp).read() != stamp_text:
         force = True
         with open(stamp, "w") as f:
-            f.write(" ".join(flags))
+            f.write(stamp_text)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cellvit_amd.h"))
     jobs = []
@@ -65,7 +73,7 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
