@@ -242,25 +242,44 @@ def test_forward_fp8_error_statistics(name):
 
 
 def test_samh_1024_fp8_instance_level_gate():
-    """Instance-level gate for the fp8 engine (SURVEY §8 row "HV/type logits": tolerance gates for fp16 / fp8 at the level the
-    product is consumed): the post-processed instance maps of the fp8 engine against those of the exact-fp32 engine on the full
-    1024^2 SAM-H tile — PQ of one against the other, as tests/test_gpu_forward.py does for fp16 (printed next to it)."""
+    """Instance-level gate for the fp8 engine (SURVEY §8 row "HV/type logits": tolerance gates at the level the product is consumed).
+    Random-weight logits hold no nuclei (the golden tile post-processes to 0-3 instances), so the gate is built from the engine's REAL
+    error field on a field of synthetic nuclei: hv' = hv_synthetic + (hv_engine - hv_fp32engine) on the full 1024^2 SAM-H tile, binary /
+    type planes as synthesised (the logit errors, max-abs < 0.25, cannot flip a trained network's margins; the HV map is the sensitive
+    input: Sobel gradients -> markers -> watershed).  PQ of the post-processed instances against the unperturbed ones, fp16 next to fp8."""
     from cellvit_amd.metrics import panoptic_quality, remap_label
+    from cellvit_amd.postproc import calculate_instance_map
+    from cellvit_amd.synth import synth_nuclei_maps
     cfg, sd, x, _ = load_case("samh_1024")
-    res = {}
-    m32 = _model(cfg, sd, "fp32")
-    b = m32(x.cuda())
-    ib, _ = m32.calculate_instance_map(b, 40)
-    ib = ib[0].numpy().astype(np.int32)
-    del m32, b
-    for dt in ("fp16", "fp8"):
+    hv = {}
+    for dt in ("fp32", "fp16", "fp8"):
         m = _model(cfg, sd, dt)
-        a = m(x.cuda())
-        ia, _ = m.calculate_instance_map(a, 40)
-        ia = ia[0].numpy().astype(np.int32)
-        assert ia.max() > 0 and ib.max() > 0
-        (dq, sq, pq), _ = panoptic_quality(remap_label(ib), remap_label(ia))
-        res[dt] = (dq, sq, pq, int(ia.max()))
-        del m, a
-    print(f"\n[samh_1024] instance maps vs the fp32 engine ({int(ib.max())} instances): (DQ, SQ, PQ, instances) fp16 {res['fp16']}  fp8 {res['fp8']}")
-    assert res["fp8"][2] > 0.80, res
+        hv[dt] = m(x.cuda())["hv_map"].float().clone()
+        del m
+    tmap, fg, hvs, _ = synth_nuclei_maps(0, size=1024, n_cells=800)
+    nt = cfg["num_nuclei_classes"] if isinstance(cfg, dict) else 6
+    fgt = torch.from_numpy(fg.astype(np.int64))
+    tmt = torch.from_numpy(tmap.astype(np.int64))
+    base = {
+        "nuclei_binary_map": (torch.nn.functional.one_hot(fgt, 2).permute(2, 0, 1)[None].float() * 4.0).to(DEV).contiguous(),
+        "nuclei_type_map": (torch.nn.functional.one_hot(tmt, nt).permute(2, 0, 1)[None].float() * 4.0).to(DEV).contiguous(),
+    }
+    hv0 = torch.from_numpy(hvs)[None].to(DEV).contiguous()
+
+    def instances(hvmap):
+        pred = dict(base)
+        pred["hv_map"] = hvmap.contiguous()
+        im, _ = calculate_instance_map(pred, nt, 40)
+        return im[0].cpu().numpy().astype(np.int32)
+
+    ref = instances(hv0)
+    assert ref.max() > 500, int(ref.max())
+    res = {}
+    for dt in ("fp16", "fp8"):
+        err = hv[dt] - hv["fp32"]
+        got = instances(hv0 + err)
+        (dq, sq, pq), _ = panoptic_quality(remap_label(ref), remap_label(got))
+        res[dt] = (round(float(dq), 4), round(float(sq), 4), round(float(pq), 4), int(got.max()), float(err.abs().max()), float(err.abs().mean()))
+    print(f"\n[samh_1024] instances under the engine's HV error field ({int(ref.max())} synthetic nuclei): (DQ, SQ, PQ, instances, max|err|, mean|err|) "
+          f"fp16 {res['fp16']}  fp8 {res['fp8']}")
+    assert res["fp16"][2] > 0.999 and res["fp8"][2] > 0.99, res       # measured: 1.0000 / 0.9998 (HV max-abs error 0.003 / 0.18)
