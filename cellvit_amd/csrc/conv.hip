@@ -93,10 +93,19 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
 
     // fragment addressing.  Halo pixel hp holds its four 16-byte pieces at byte hp*64 + ((piece ^ swz(hp)) << 4); a
     // lane reads piece g of pixel a_hp[i] + (dy*HW_ + dx).  Filter row n of tap t sits at t*4096 + n*64 + swizzled piece.
-    int a_hp[4];                                     // halo pixel of (fragment i, lane) for the centre tap
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a_hp[i] = (2 * wave + (i >> 1) + 1) * HW_ + ((i & 1) * 16 + li + 1);
+    // (address form as in conv3x3_halo4_kernel below: a register per fragment + the read's immediate offset + ONE swizzle bit taken from a
+    //  per-lane mask indexed by the displacement class E = (2 * row + dx) mod 8 — two instructions per read instead of six)
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem;
+    unsigned a_base[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        a_base[i] = lds0 + (unsigned)(((2 * wave + (i >> 1) + 1) * HW_ + ((i & 1) * 16 + li + 1) - (HW_ + 1)) * 64) + ((unsigned)(g & 1) << 4);
+    unsigned a_u5 = 0u;
+    {
+        const int r8 = ((2 * wave + 1) * HW_ + li + 1) & 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a_u5 |= (unsigned)((((r8 + e) >> 2) & 1) ^ ((g >> 1) & 1)) << (5 + e);
+    }
     unsigned b_ad[4];                                // LDS byte address of W fragment j, tap 0, buffer 0
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int n = j * 16 + li; b_ad[j] = lds0 + HALO_BYTES + n * 64 + ((g ^ swz(n)) << 4); }
@@ -111,19 +120,18 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
                  : "+v"(Af[S][0]), "+v"(Af[S][1]), "+v"(Af[S][2]), "+v"(Af[S][3]), "+v"(Bf[S][0]), "+v"(Bf[S][1]), \
                    "+v"(Bf[S][2]), "+v"(Bf[S][3])                                                               \
                  :: "memory")
-    // reads of tap TAP into register set S; bbase = byte offset of the stage buffer
+#define CV_RD_A8(i, TAP, S)                                                                                     \
+    do {                                                                                                        \
+        constexpr int e_ = (2 * (((i) >> 1) + (TAP) / 3 - 1) + ((TAP) % 3 - 1) + 16) & 7;                       \
+        unsigned ad;                                                                                            \
+        asm volatile("v_lshrrev_b32 %0, %1, %2\n\tv_and_or_b32 %0, %0, 32, %3" : "=&v"(ad) : "n"(e_), "v"(a_u5), "v"(a_cur[i])); \
+        CV_DSR(Af[S][i], ad, (((TAP) / 3 - 1) * HW_ + ((TAP) % 3 - 1) + HW_ + 1) * 64);                         \
+    } while (0)
+    // reads of tap TAP into register set S from the stage buffer a_cur / b_cur point into
 #define CV_READ_TAP(TAP, S, bbase)                                                                              \
     do {                                                                                                        \
-        constexpr int doff = ((TAP) / 3 - 1) * HW_ + ((TAP) % 3 - 1);                                           \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-            const unsigned ad = b_ad[j] + (bbase);                                                              \
-            CV_DSR(Bf[S][j], ad, (TAP) * 4096);                                                                 \
-        }                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
-            const int hp = a_hp[i] + doff;                                                                      \
-            const unsigned ad = lds0 + (bbase) + hp * 64 + ((g ^ swz(hp)) << 4);                                \
-            CV_DSR(Af[S][i], ad, 0);                                                                            \
-        }                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) CV_DSR(Bf[S][j], b_cur[j], (TAP) * 4096);                 \
+        CV_RD_A8(0, TAP, S); CV_RD_A8(1, TAP, S); CV_RD_A8(2, TAP, S); CV_RD_A8(3, TAP, S);                     \
     } while (0)
 #define CV_MMA_TAP(S)                                                                                           \
     do {                                                                                                        \
@@ -176,6 +184,9 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         const unsigned bbase = buf * CONV_LDS;
+        unsigned a_cur[4], b_cur[4];                     // this chunk's stage buffer (opaque: the 36 tap addresses must not be hoisted)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a_cur[i] = a_base[i] + bbase; b_cur[i] = b_ad[i] + bbase; asm volatile("" : "+v"(a_cur[i]), "+v"(b_cur[i])); }
         CV_READ_TAP(0, 0, bbase);                        // first tap of the chunk (its latency is exposed once per chunk)
         if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -314,10 +325,23 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
 
-    int a_hp[8];                                     // halo pixel of (fragment i, lane) for the centre tap: rows 4w .. 4w+3
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a_hp[i] = (4 * wave + (i >> 1) + 1) * HW_ + ((i & 1) * 16 + li + 1);
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem;
+    // A-fragment addresses.  Halo pixel hp keeps piece q at byte hp*64 + ((q ^ swz(hp)) << 4), swz(hp) = 2 * bit 2 of hp, so a lane's
+    // address for (fragment i, tap) is  [hp0(i) - 35]*64 + ((g & 1) << 4)  +  (tap displacement + 35)*64  with bit 5 = g's bit 1 ^ bit 2 of hp.
+    // The first term is a register per fragment, the second the read's immediate offset, and bit 2 of hp = hp0(0) + 34*k + 16*(i&1) + dx
+    // depends on the lane only through hp0(0) mod 8: the eight possible answers (E = (2k + dx) mod 8) are one per-lane bit mask, so a read
+    // costs a shift and an and-or instead of six address instructions (measured: 4.2 VALU instructions per MFMA in this kernel, and VALU
+    // work beyond two instructions per MFMA gap is not hidden — profiles/r03_probe_mfma_valu_overlap.txt).
+    unsigned a_base[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        a_base[i] = lds0 + (unsigned)(((4 * wave + (i >> 1) + 1) * HW_ + ((i & 1) * 16 + li + 1) - (HW_ + 1)) * 64) + ((unsigned)(g & 1) << 4);
+    unsigned a_u5 = 0u;                              // bit 5 + E: bit 1 of the physical piece for displacement class E
+    {
+        const int r8 = ((4 * wave + 1) * HW_ + li + 1) & 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a_u5 |= (unsigned)((((r8 + e) >> 2) & 1) ^ ((g >> 1) & 1)) << (5 + e);
+    }
     unsigned b_ad[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int n = j * 16 + li; b_ad[j] = lds0 + HALO_BYTES + n * 64 + ((g ^ swz(n)) << 4); }
@@ -335,9 +359,10 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
 #define CV4_RD_A(i, TAP)                                                                                         \
     do {                                                                                                         \
         constexpr int doff_ = ((TAP) / 3 - 1) * HW_ + ((TAP) % 3 - 1);                                           \
-        const int hp = a_hp[i] + doff_;                                                                          \
-        const unsigned ad = lds0 + hp * 64 + ((g ^ swz(hp)) << 4);                                               \
-        CV_DSR(Af[i], ad, 0);                                                                                    \
+        constexpr int e_ = (2 * (((i) >> 1) + (TAP) / 3 - 1) + ((TAP) % 3 - 1) + 16) & 7;                        \
+        unsigned ad;    /* asm: two instructions per read, neither hoisted nor shared across taps (72 addresses would not fit) */ \
+        asm volatile("v_lshrrev_b32 %0, %1, %2\n\tv_and_or_b32 %0, %0, 32, %3" : "=&v"(ad) : "n"(e_), "v"(a_u5), "v"(a_base[i]));  \
+        CV_DSR(Af[i], ad, (doff_ + HW_ + 1) * 64);                                                               \
     } while (0)
 #define CV4_RD_LO(TAP)                                                                                           \
     do {                                                                                                         \
@@ -402,7 +427,7 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
         __syncthreads();
         // (opaque per chunk: keeps the 72 tap addresses from being hoisted out of the loop into registers)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(a_hp[i]));
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(a_base[i]));
         CV4_RD_LO(0);
         CV4_STEP(0, 0); CV4_STEP(1, 0); CV4_STEP(2, 0);
         CV4_STEP(3, 0); CV4_STEP(4, 0); CV4_STEP(5, 0);
