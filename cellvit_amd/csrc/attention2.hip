@@ -147,7 +147,11 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     if (BIAS != 0) {
         constexpr int RCP = (BIAS == 1) ? PE1 : RC2;
         T* myrc = Rc + (wave * QW) * RCP;
-        for (int i = lane; i < QW * RCP; i += 64) myrc[i] = TR::from_float(0.f);
+        if constexpr (sizeof(T) == 2 && (QW * RCP) % 8 == 0) {            // 16-byte stores (rows are 16-byte multiples)
+            for (int i = lane; i < QW * RCP / 8; i += 64) store_piece(myrc + i * 8, zero_piece());
+        } else {
+            for (int i = lane; i < QW * RCP; i += 64) myrc[i] = TR::from_float(0.f);
+        }
         // BIAS 1 (2*K - 1 <= 32 table rows): both tables are staged once per block, coalesced, into LDS as T-typed rows of
         // pitch PK (zero padded to 32 rows x HDP columns; aliased onto the K / V^T tile area, which is idle until the key
         // loop), so that the table fragments below are single 16-byte LDS reads instead of 8 scattered global loads.
@@ -185,9 +189,10 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
                     if (STAGED) {
                         tf[ks] = TR::load_frag(Ts + (tbl * 32 + j) * PK + d0);
                     } else if (j < nj && d0 < HD) {
-                        const float* src = tab + (long)j * HD + d0;
+                        const float* src = tab + (long)j * HD + d0;      // (HD % 8 == 0: two 16-byte loads)
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) set_frag<T>(tf[ks], e, src[e]);
+                        for (int e = 0; e < 4; ++e) { set_frag<T>(tf[ks], e, t0[e]); set_frag<T>(tf[ks], 4 + e, t1[e]); }
                     }
                 }
 #pragma unroll
