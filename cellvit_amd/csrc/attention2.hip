@@ -180,6 +180,15 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             const int nj = 2 * Ksz - 1;
 #pragma unroll 1
             for (int jb = 0; jb * 16 < nj; ++jb) {
+                if (BIAS == 2) {
+                    // only the table rows j = c - kk + Ksz - 1 with 0 <= kk < Ksz are ever scattered: for the wave's 32 consecutive
+                    // queries c spans [clo, chi] (one grid row: a single qy; 32 consecutive qx), i.e. rows [clo, chi + Ksz - 1] —
+                    // 16-row blocks outside that band are skipped (wave-uniform: 5 of 8 blocks for the row table, 6 for the column one)
+                    const int qlo = min(q0, p.L - 1), qhi = min(q0 + QW - 1, p.L - 1);
+                    const int clo = tbl == 0 ? qlo / p.KW : qlo % p.KW, chi = tbl == 0 ? qhi / p.KW : (qlo / p.KW == qhi / p.KW ? qhi % p.KW : p.KW - 1);
+                    const int cl2 = tbl == 0 ? clo : (qlo / p.KW == qhi / p.KW ? clo : 0);
+                    if (jb * 16 + 15 < cl2 || jb * 16 > chi + Ksz - 1) continue;
+                }
                 Frag tf[NKS];
                 const int j = jb * 16 + li;
 #pragma unroll
