@@ -90,6 +90,16 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
         tb = m_first / p.ntok; tt = m_first - tb * p.ntok;
         if (p.win > 0) { tgy = tt / p.gw; tgx = tt - tgy * p.gw; }
     }
+    // OUT_CONVT: input pixel m -> (image cb, row cy, column cx), likewise walked 16 pixels per fragment row: the two integer divisions per row
+    // were ~560 of the ~1000 VALU instructions of this epilogue per tile and wave, next to 128-256 MFMAs for the K = 128 / 256 layers
+    int cb = 0, cy = 0, cx = 0, ccout = 1, cdd = 0, cco = 0;
+    if (OMODE == OUT_CONVT) {
+        const int m_first = mrow0 + li, hw = p.H * p.Wd;
+        cb = m_first / hw;
+        const int r2 = m_first - cb * hw;
+        cy = r2 / p.Wd; cx = r2 - cy * p.Wd;
+        ccout = p.N >> 2; cdd = n / ccout; cco = n - cdd * ccout;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = mrow0 + i * 16 + li;
@@ -179,11 +189,10 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
             // ConvTranspose2d k2 s2: row m = input pixel (b, y, x), column n = (dy*2 + dx) * Cout + co; the lane's 16 columns
             // are 16 consecutive co of one (dy, dx) (Cout % 16 == 0): one 32-byte run of output pixel (2y + dy, 2x + dx).
             // The up-sampled activation is streamed out once and read much later: nontemporal stores.
-            const int cout = p.N >> 2;
-            const int dd = n / cout, co = n - dd * cout;
-            const int hw = p.H * p.Wd;
-            const int b = m / hw, r2 = m - b * hw;
-            const int y = r2 / p.Wd, x = r2 - y * p.Wd;
+            const int cout = ccout, dd = cdd, co = cco;
+            const int b = cb, y = cy, x = cx;
+            cx += 16;                                   // next fragment row: 16 input pixels further (raster order over images)
+            while (cx >= p.Wd) { cx -= p.Wd; if (++cy >= p.H) { cy = 0; ++cb; } }
             half_t* o = reinterpret_cast<half_t*>(p.out) +
                         (((long)b * 2 * p.H + 2 * y + (dd >> 1)) * (2 * p.Wd) + 2 * x + (dd & 1)) * cout + co;
             if (p.comp_bias) {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel instruction mix / busy cycles (PMC passes, kernel-trace only) of the round-3 tree
-OUT=gpurun_out/r03w; mkdir -p $OUT
+OUT=gpurun_out/r03w2; mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$(pwd)
 i=0
