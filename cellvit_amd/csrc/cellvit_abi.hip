@@ -308,8 +308,11 @@ int pack_ln(cv_handle* h, const std::string& p, int C, LNW* out) {
 
 // Conv2d 3x3 [Cout, Cin, 3, 3] (+bias) (+BatchNorm2d eval) -> [Cout, 9*Cpad], k = tap*Cpad + c.
 // conv_key / bn_key: full module prefixes; bn_key empty = no BN; has_bias false = no conv bias.
+// Cout_pad > Cout: the layer is packed with Cout_pad output channels, the extra ones with zero filters and zero bias (their activations
+// are exact zeros).  src1 > 0: the input is the concat of two tensors of src1 and Cin - src1 real channels, each stored with src_pad
+// channels — source 2's filter columns start at src_pad (Cpad = 2 * src_pad).  (CellViT-256's 312-channel bottleneck stored as 320.)
 int pack_conv3(cv_handle* h, const std::string& conv_key, const std::string& bn_key, int Cin, int Cout, int Cpad,
-               bool has_bias, int relu, ConvW* out) {
+               bool has_bias, int relu, ConvW* out, int Cout_pad = 0, int src1 = 0, int src_pad = 0) {
     const HostTensor* w = find(h, conv_key + ".weight", {Cout, Cin, 3, 3}); CVA_NEED(w);
     const HostTensor* cb = nullptr;
     if (has_bias) { cb = find(h, conv_key + ".bias", {Cout}); CVA_NEED(cb); }
@@ -321,22 +324,27 @@ int pack_conv3(cv_handle* h, const std::string& conv_key, const std::string& bn_
         var = find(h, bn_key + ".running_var", {Cout}); CVA_NEED(var);
     }
     const int K = 9 * Cpad;
-    std::vector<float> wk((size_t)Cout * K, 0.f), bias(Cout, 0.f);
+    const int Co = Cout_pad > Cout ? Cout_pad : Cout;
+    std::vector<float> wk((size_t)Co * K, 0.f), bias(Co, 0.f);
     for (int co = 0; co < Cout; ++co) {
         double scale = 1.0, shift = 0.0;
         if (g) {
             scale = (double)g->data[co] / std::sqrt((double)var->data[co] + BN_EPS);
             shift = (double)be->data[co] - (double)mu->data[co] * scale;
         }
-        for (int ci = 0; ci < Cin; ++ci)
+        for (int ci = 0; ci < Cin; ++ci) {
+            const int cp = (src1 > 0 && ci >= src1) ? src_pad + (ci - src1) : ci;
             for (int t = 0; t < 9; ++t)
-                wk[(size_t)co * K + t * Cpad + ci] = (float)((double)w->data[((size_t)co * Cin + ci) * 9 + t] * scale);
+                wk[(size_t)co * K + t * Cpad + cp] = (float)((double)w->data[((size_t)co * Cin + ci) * 9 + t] * scale);
+        }
         bias[co] = (float)((cb ? (double)cb->data[co] : 0.0) * scale + shift);
     }
-    out->Cout = Cout; out->Ctot = Cpad; out->K = K; out->relu = relu; out->Cin_real = Cin;
+    out->Cout = Co; out->Ctot = Cpad; out->K = K; out->relu = relu; out->Cin_real = Cin;
     out->ldw = round_up(K, bk_of(h->cfg.compute_dtype));
-    CVA_TRY(upload_matrix(h, wk.data(), Cout, K, out->ldw, &out->W));
-    if (has_bias || g) CVA_TRY(upload_f32(h, bias.data(), Cout, &out->bias));
+    CVA_TRY(upload_matrix(h, wk.data(), Co, K, out->ldw, &out->W));
+    if (has_bias || g) CVA_TRY(upload_f32(h, bias.data(), Co, &out->bias));
+    const int Cout_real = Cout; Cout = Co;       // (the chunk-major copy below covers the packed rows)
+    (void)Cout_real;
     const int chunks = Cpad / 64;
     if (!is_f32(h->cfg.compute_dtype) && Cout % 256 == 0 && Cpad % 64 == 0 && chunks >= 2 && (chunks & (chunks - 1)) == 0 && out->ldw == K) {
         std::vector<float> wkm((size_t)Cout * K);
@@ -350,19 +358,21 @@ int pack_conv3(cv_handle* h, const std::string& conv_key, const std::string& bn_
 }
 
 // ConvTranspose2d k2 s2 [Cin, Cout, 2, 2] -> [4*Cout, Cin], n = (dy*2+dx)*Cout + co
-int pack_convT(cv_handle* h, const std::string& key, int Cin, int Cout, ConvTW* out) {
+// Cin_pad / Cout_pad (0 = none): input stored with Cin_pad channels (zero filter columns), output written with Cout_pad channels (zero rows, zero bias)
+int pack_convT(cv_handle* h, const std::string& key, int Cin, int Cout, ConvTW* out, int Cin_pad = 0, int Cout_pad = 0) {
     const HostTensor* w = find(h, key + ".weight", {Cin, Cout, 2, 2}); CVA_NEED(w);
     const HostTensor* b = find(h, key + ".bias", {Cout}); CVA_NEED(b);
-    std::vector<float> wk((size_t)4 * Cout * Cin), b4((size_t)4 * Cout);
+    const int Ci = Cin_pad > Cin ? Cin_pad : Cin, Co = Cout_pad > Cout ? Cout_pad : Cout;
+    std::vector<float> wk((size_t)4 * Co * Ci, 0.f), b4((size_t)4 * Co, 0.f);
     for (int dd = 0; dd < 4; ++dd)
         for (int co = 0; co < Cout; ++co) {
-            b4[(size_t)dd * Cout + co] = b->data[co];
+            b4[(size_t)dd * Co + co] = b->data[co];
             for (int ci = 0; ci < Cin; ++ci)
-                wk[((size_t)dd * Cout + co) * Cin + ci] = w->data[((size_t)ci * Cout + co) * 4 + dd];
+                wk[((size_t)dd * Co + co) * Ci + ci] = w->data[((size_t)ci * Cout + co) * 4 + dd];
         }
-    out->Cin = Cin; out->Cout = Cout; out->ldw = round_up(Cin, bk_of(h->cfg.compute_dtype));
-    CVA_TRY(upload_matrix(h, wk.data(), 4 * Cout, Cin, out->ldw, &out->W));
-    CVA_TRY(upload_f32(h, b4.data(), (size_t)4 * Cout, &out->bias4));
+    out->Cin = Ci; out->Cout = Co; out->ldw = round_up(Ci, bk_of(h->cfg.compute_dtype));
+    CVA_TRY(upload_matrix(h, wk.data(), 4 * Co, Ci, out->ldw, &out->W));
+    CVA_TRY(upload_f32(h, b4.data(), (size_t)4 * Co, &out->bias4));
     return CV_OK;
 }
 
@@ -471,12 +481,14 @@ int pack_deconv_comp(cv_handle* h, const std::string& convT_key, const std::stri
     return CV_OK;
 }
 
-int pack_conv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvW* out, int Cpad = 0) {
-    return pack_conv3(h, p + ".block.0", p + ".block.1", Cin, Cout, Cpad ? Cpad : Cin, true, 1, out);
+int pack_conv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvW* out, int Cpad = 0, int Cout_pad = 0, int src1 = 0, int src_pad = 0) {
+    return pack_conv3(h, p + ".block.0", p + ".block.1", Cin, Cout, Cpad ? Cpad : Cin, true, 1, out, Cout_pad, src1, src_pad);
 }
-int pack_deconv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvTW* t, ConvW* c, DeconvCompW* k) {
-    CVA_TRY(pack_convT(h, p + ".block.0", Cin, Cout, t));
-    CVA_TRY(pack_conv3(h, p + ".block.1", p + ".block.2", Cout, Cout, Cout, true, 1, c));
+// Cout_pad: the block's channel count as stored (see stored_channels)
+int pack_deconv_block(cv_handle* h, const std::string& p, int Cin, int Cout, ConvTW* t, ConvW* c, DeconvCompW* k, int Cout_pad = 0) {
+    const int Co = Cout_pad > Cout ? Cout_pad : Cout;
+    CVA_TRY(pack_convT(h, p + ".block.0", Cin, Cout, t, 0, Co));
+    CVA_TRY(pack_conv3(h, p + ".block.1", p + ".block.2", Cout, Cout, Co, true, 1, c, Co));
     return pack_deconv_comp(h, p + ".block.0", p + ".block.1", p + ".block.2", Cin, Cout, 0, Cout, k);
 }
 
@@ -484,14 +496,20 @@ void skip_dims(const cv_config& c, int* s11, int* s12, int* bott) {   // cellvit
     if (c.embed_dim < 512) { *s11 = 256; *s12 = 128; *bott = 312; } else { *s11 = 512; *s12 = 256; *bott = 512; }
 }
 
+// Channel count the bottleneck-width tensors are STORED with: CellViT-256's 312 channels are not a multiple of the convolution kernels'
+// 32-channel chunk (its four 3x3 layers per branch ran the generic gather kernel at 645 TFLOP/s); the fp16 engines store them as 320 with
+// exact zeros in the pad channels (zero filter rows / columns, zero bias), which puts those layers on the halo kernels.
+int stored_channels(const cv_handle* h, int c) { return (is_f32(h->cfg.compute_dtype) || c % 32 == 0) ? c : round_up(c, 64); }
+
 int pack_branch(cv_handle* h, const std::string& p, int n_out, BranchW* b) {
     const int D = h->cfg.embed_dim;
     int s11, s12, bott; skip_dims(h->cfg, &s11, &s12, &bott);
-    CVA_TRY(pack_convT(h, p + ".bottleneck_upsampler", D, bott, &b->up4));
-    CVA_TRY(pack_conv_block(h, p + ".decoder3_upsampler.0", 2 * bott, bott, &b->d3[0]));
-    CVA_TRY(pack_conv_block(h, p + ".decoder3_upsampler.1", bott, bott, &b->d3[1]));
-    CVA_TRY(pack_conv_block(h, p + ".decoder3_upsampler.2", bott, bott, &b->d3[2]));
-    CVA_TRY(pack_convT(h, p + ".decoder3_upsampler.3", bott, 256, &b->up3));
+    const int bp = stored_channels(h, bott);
+    CVA_TRY(pack_convT(h, p + ".bottleneck_upsampler", D, bott, &b->up4, 0, bp));
+    CVA_TRY(pack_conv_block(h, p + ".decoder3_upsampler.0", 2 * bott, bott, &b->d3[0], 2 * bp, bp, bott, bp));
+    CVA_TRY(pack_conv_block(h, p + ".decoder3_upsampler.1", bott, bott, &b->d3[1], bp, bp));
+    CVA_TRY(pack_conv_block(h, p + ".decoder3_upsampler.2", bott, bott, &b->d3[2], bp, bp));
+    CVA_TRY(pack_convT(h, p + ".decoder3_upsampler.3", bott, 256, &b->up3, bp, 0));
     CVA_TRY(pack_conv_block(h, p + ".decoder2_upsampler.0", 512, 256, &b->d2[0]));
     CVA_TRY(pack_conv_block(h, p + ".decoder2_upsampler.1", 256, 256, &b->d2[1]));
     CVA_TRY(pack_convT(h, p + ".decoder2_upsampler.2", 256, 128, &b->up2));
@@ -704,6 +722,7 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
     const int D = c.embed_dim, heads = c.num_heads, H = g.H, W = g.W, P = g.P, ntok = g.ntok;
     const int M = B * ntok, hid = D * c.mlp_ratio;
     int s11, s12, bott; skip_dims(c, &s11, &s12, &bott);
+    bott = stored_channels(h, bott);                  // channel count of the bottleneck-width tensors as stored
 
     // ---- patch embedding + positional table (F1/F2/F2') ----
     CVA_LAUNCH(launch_patchify<T>(x, u8, h->patchA, B, H, W, st));
@@ -963,7 +982,7 @@ extern "C" int cv_finalize(cv_handle* h) {
     CVA_TRY(pack_deconv_block(h, "decoder1.2", s12, 128, &h->dec1_t[2], &h->dec1_c[2], &h->dec1_k[2]));
     CVA_TRY(pack_deconv_block(h, "decoder2.0", D, s11, &h->dec2_t[0], &h->dec2_c[0], &h->dec2_k[0]));
     CVA_TRY(pack_deconv_block(h, "decoder2.1", s11, 256, &h->dec2_t[1], &h->dec2_c[1], &h->dec2_k[1]));
-    CVA_TRY(pack_deconv_block(h, "decoder3.0", D, bott, &h->dec3_t[0], &h->dec3_c[0], &h->dec3_k[0]));
+    CVA_TRY(pack_deconv_block(h, "decoder3.0", D, bott, &h->dec3_t[0], &h->dec3_c[0], &h->dec3_k[0], stored_channels(h, bott)));
     const int nb = 2 + (c.regression_loss ? 2 : 0);
     CVA_TRY(pack_branch(h, "nuclei_binary_map_decoder", nb, &h->branch[0]));
     CVA_TRY(pack_branch(h, "hv_map_decoder", 2, &h->branch[1]));
@@ -1065,7 +1084,10 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
     CVA_TRY(A(&h->skip[0], (size_t)B * hw * 64 * es));
     CVA_TRY(A(&h->skip[1], (size_t)B * hw / 4 * 128 * es));
     CVA_TRY(A(&h->skip[2], (size_t)B * hw / 16 * 256 * es));
+    const int bott_real = bott;
+    bott = stored_channels(h, bott);
     CVA_TRY(A(&h->skip[3], (size_t)B * hw / 64 * bott * es));
+    (void)bott_real;
     // scratch: the widest intermediate is 64 channels at full resolution (or s11/bott at 1/8)
     size_t smax = hw * 64;
     smax = std::max(smax, hw / 64 * (size_t)std::max(s11, bott));
@@ -1191,7 +1213,20 @@ extern "C" int cv_debug_read(cv_handle* h, const char* name, float* host_dst, si
     else if (s == "skip0") { src = h->skip[0]; n = B * hw * 64; }
     else if (s == "skip1") { src = h->skip[1]; n = B * hw / 4 * 128; }
     else if (s == "skip2") { src = h->skip[2]; n = B * hw / 16 * 256; }
-    else if (s == "skip3") { src = h->skip[3]; n = B * hw / 64 * bott; }
+    else if (s == "skip3") {
+        src = h->skip[3]; n = B * hw / 64 * bott;
+        const int bp = stored_channels(h, bott);
+        if (bp != bott) {       // stored with pad channels: compact the real ones (debug path: a copy, then the common conversion below)
+            if (n_out) *n_out = n;
+            if (n > capacity) { cva_set_error("capacity too small: need %zu", n); return CV_ERR_INVALID; }
+            CVA_CHECK_HIP(hipDeviceSynchronize());
+            std::vector<half_t> tmp((size_t)B * hw / 64 * bp);
+            CVA_CHECK_HIP(hipMemcpy(tmp.data(), src, tmp.size() * 2, hipMemcpyDeviceToHost));
+            for (size_t px = 0; px < (size_t)B * hw / 64; ++px)
+                for (int ch = 0; ch < bott; ++ch) host_dst[px * bott + ch] = (float)tmp[px * bp + ch];
+            return CV_OK;
+        }
+    }
     else { cva_set_error("unknown tap '%s' (debug=%d)", name, h->debug); return CV_ERR_INVALID; }
     if (n_out) *n_out = n;
     if (n > capacity) { cva_set_error("capacity too small: need %zu", n); return CV_ERR_INVALID; }
