@@ -343,16 +343,14 @@ int pack_conv3(cv_handle* h, const std::string& conv_key, const std::string& bn_
     out->ldw = round_up(K, bk_of(h->cfg.compute_dtype));
     CVA_TRY(upload_matrix(h, wk.data(), Co, K, out->ldw, &out->W));
     if (has_bias || g) CVA_TRY(upload_f32(h, bias.data(), Co, &out->bias));
-    const int Cout_real = Cout; Cout = Co;       // (the chunk-major copy below covers the packed rows)
-    (void)Cout_real;
-    const int chunks = Cpad / 64;
-    if (!is_f32(h->cfg.compute_dtype) && Cout % 256 == 0 && Cpad % 64 == 0 && chunks >= 2 && (chunks & (chunks - 1)) == 0 && out->ldw == K) {
-        std::vector<float> wkm((size_t)Cout * K);
-        for (int co = 0; co < Cout; ++co)
+    const int chunks = Cpad / 64;      // (chunk-major copy of the packed rows for the implicit GEMM)
+    if (!is_f32(h->cfg.compute_dtype) && Co % 256 == 0 && Cpad % 64 == 0 && chunks >= 2 && (chunks & (chunks - 1)) == 0 && out->ldw == K) {
+        std::vector<float> wkm((size_t)Co * K);
+        for (int co = 0; co < Co; ++co)
             for (int ch = 0; ch < chunks; ++ch)
                 for (int t = 0; t < 9; ++t)
                     memcpy(&wkm[(size_t)co * K + ((size_t)ch * 9 + t) * 64], &wk[(size_t)co * K + (size_t)t * Cpad + ch * 64], 64 * sizeof(float));
-        CVA_TRY(upload_matrix(h, wkm.data(), Cout, K, out->ldw, &out->Wkm));
+        CVA_TRY(upload_matrix(h, wkm.data(), Co, K, out->ldw, &out->Wkm));
     }
     return CV_OK;
 }
