@@ -82,6 +82,7 @@ struct GemmParams {
     int m_valid, n_valid;
     int epi_vec;                     // 1: LDS-staged 16-byte epilogue stores (set by launch_gemm)
     int dbg;                         // experiment switches (CVA_GEMM_DBG): 1 no staging, 2 no LDS reads, 4 no L2 prefetch
+    int stagger;                     // experiment (ablation builds, CVA_GEMM_STAGGER): start delay spread in units of 10 ns; > 0 per XCD, < 0 per workgroup
 };
 
 template <typename T> int launch_gemm(const GemmParams& p, int a_mode, hipStream_t stream);

@@ -159,6 +159,7 @@ template <typename T>
 int launch_gemm(const GemmParams& p_in, int a_mode, hipStream_t stream) {
     GemmParams p = p_in;
     { static const int dbg = cva_env_int("CVA_GEMM_DBG", 0); p.dbg = dbg; }   // ablation builds only (common.h)
+    { static const int stg = cva_env_int("CVA_GEMM_STAGGER", 0); p.stagger = stg; }
     if (((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) <= 0) return 0;
     {   // vectorised (LDS-staged) epilogue preconditions
         static const int epi = cva_env_int("CVA_EPI", 1);

@@ -447,6 +447,14 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     int m0, n0; bool swap;
     int tile = blockIdx.x;
     int slot = 0;
+#ifdef CVA_ABLATION
+    if (p.stagger) {       // experiment: de-phase the workgroups' epilogues (stores of all CUs otherwise hit HBM in the same instant)
+        const long spread = p.stagger > 0 ? p.stagger : -p.stagger;
+        const long target = p.stagger > 0 ? spread * (blockIdx.x & 7) / 8 : spread * (long)(((blockIdx.x & 7) * 32 + (blockIdx.x >> 3)) & 255) / 256;
+        const long t0 = (long)wall_clock64();
+        while ((long)wall_clock64() - t0 < target) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     tile_setup(tile, m0, n0, swap);
     stage_prologue(n0, swap, slot);
     for (; tile < ntiles; tile += gridDim.x, slot ^= 1) {

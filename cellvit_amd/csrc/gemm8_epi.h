@@ -137,6 +137,10 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 w = {v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+#ifdef CVA_ABLATION
+                    if (p.dbg & 8192) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o + q * 4), "v"(w) : "memory"); continue; }
+                    if (p.dbg & 16384) { __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(o + q * 4)); continue; }
+#endif
                     *reinterpret_cast<f32x4*>(o + q * 4) = w;
                 }
             } else {
@@ -156,6 +160,8 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
                         *reinterpret_cast<half8_t*>(o + rsh + ((lil & 1) ? 8 : 0)) = w;
                         continue;
                     }
+                    if (p.dbg & 8192) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o + q * 8), "v"(w) : "memory"); continue; }
+                    if (p.dbg & 16384) { __builtin_nontemporal_store(w, reinterpret_cast<half8_t*>(o + q * 8)); continue; }
 #endif
                     *reinterpret_cast<half8_t*>(o + q * 8) = w;
                 }

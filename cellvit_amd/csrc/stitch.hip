@@ -76,6 +76,50 @@ __global__ void k_grid_pairs(const int32_t* __restrict__ bbox, int n, Grid g, co
         }
 }
 
+// Rings that are not simple (reference: `if not poly.is_valid` -> Polygon.buffer(0) -> largest part, cell_detection.py:689-704).
+// The contours are outer borders traced on the pixel lattice: they never cross themselves but can TOUCH themselves (a blob that is
+// 8-connected through a diagonal pinch passes the pinch pixel twice; a one-pixel-wide spur is walked out and back).  flags[i] = 1
+// when two non-adjacent edges of ring i share a point, two consecutive edges fold back onto each other, or a vertex repeats —
+// one thread per ring, O(edges^2) integer orientation tests (a nucleus outline has 10-60 edges).  The flagged rings (a handful
+// per slide) are repaired by host code of the library (cv_stitch_repair_rings).
+__device__ __forceinline__ long long orient2(int ax, int ay, int bx, int by, int cx, int cy) {
+    return (long long)(bx - ax) * (cy - ay) - (long long)(by - ay) * (cx - ax);
+}
+__device__ __forceinline__ bool in_box(int ax, int ay, int bx, int by, int px, int py) {
+    return px >= min(ax, bx) && px <= max(ax, bx) && py >= min(ay, by) && py <= max(ay, by);
+}
+__global__ void k_ring_flags(const int64_t* __restrict__ off, const int32_t* __restrict__ xy, int n, uint8_t* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long o = off[i];
+    const int m = (int)(off[i + 1] - o);
+    const int32_t* p = xy + 2 * o;
+    bool bad = false;
+    for (int a = 0; a < m && !bad; ++a) {
+        const int a1 = a + 1 == m ? 0 : a + 1;
+        const int px = p[2 * a], py = p[2 * a + 1], qx = p[2 * a1], qy = p[2 * a1 + 1];
+        if (px == qx && py == qy) { bad = m > 1; break; }                 // repeated consecutive vertex
+        {   // the next edge folds back onto this one (spur tip)
+            const int a2 = a1 + 1 == m ? 0 : a1 + 1;
+            const int rx = p[2 * a2], ry = p[2 * a2 + 1];
+            if (m >= 3 && orient2(px, py, qx, qy, rx, ry) == 0 &&
+                (long long)(qx - px) * (rx - qx) + (long long)(qy - py) * (ry - qy) < 0) { bad = true; break; }
+        }
+        for (int b = a + 2; b < m; ++b) {
+            if (a == 0 && b == m - 1) continue;                          // adjacent through the closing edge
+            const int b1 = b + 1 == m ? 0 : b + 1;
+            const int rx = p[2 * b], ry = p[2 * b + 1], sx = p[2 * b1], sy = p[2 * b1 + 1];
+            if (max(px, qx) < min(rx, sx) || max(rx, sx) < min(px, qx) || max(py, qy) < min(ry, sy) || max(ry, sy) < min(py, qy)) continue;
+            const long long o1 = orient2(px, py, qx, qy, rx, ry), o2 = orient2(px, py, qx, qy, sx, sy);
+            const long long o3 = orient2(rx, ry, sx, sy, px, py), o4 = orient2(rx, ry, sx, sy, qx, qy);
+            if (((o1 > 0) != (o2 > 0)) && o1 != 0 && o2 != 0 && ((o3 > 0) != (o4 > 0)) && o3 != 0 && o4 != 0) { bad = true; break; }
+            if ((o1 == 0 && in_box(px, py, qx, qy, rx, ry)) || (o2 == 0 && in_box(px, py, qx, qy, sx, sy)) ||
+                (o3 == 0 && in_box(rx, ry, sx, sy, px, py)) || (o4 == 0 && in_box(rx, ry, sx, sy, qx, qy))) { bad = true; break; }
+        }
+    }
+    flags[i] = bad ? 1 : 0;
+}
+
 // 2 * signed area of the closed polygon through the contour points: integer arithmetic, exact
 __global__ void k_poly_area(const int64_t* __restrict__ off, const int32_t* __restrict__ xy, int n, double* __restrict__ area) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,7 +274,10 @@ extern "C" int cv_stitch_overlaps(const int32_t* bbox, const int64_t* ct_off, co
         hipLaunchKernelGGL(k_poly_area, dim3(nb), dim3(T), 0, st, ct_off, ct_xy, n, area);
         ST_CHECK(hipMemcpyAsync(&np, np_dev, 4, hipMemcpyDeviceToHost, st));
         ST_CHECK(hipStreamSynchronize(st));
-        if (np > cap) { cva_set_error("cv_stitch_overlaps: %d candidate pairs exceed the capacity %d", np, cap); rc = CV_ERR_SHAPE; goto done; }
+        if (np > cap) {      // the caller retries with the count returned here
+            *n_pairs_host = np;
+            cva_set_error("cv_stitch_overlaps: %d candidate pairs exceed the capacity %d", np, cap); rc = CV_ERR_SHAPE; goto done;
+        }
         if (np > 0) hipLaunchKernelGGL(k_pair_inter, dim3((np + 63) / 64), dim3(64), 0, st, pairs, np, ct_off, ct_xy, inter);
         ST_CHECK(hipGetLastError());
         ST_CHECK(hipStreamSynchronize(st));
@@ -246,11 +293,126 @@ done:
     return rc;
 }
 
+extern "C" int cv_stitch_ring_flags(const int64_t* ct_off, const int32_t* ct_xy, int n, uint8_t* flags, void* stream_) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    if (n <= 0) return CV_OK;
+    if (!ct_off || !ct_xy || !flags) { cva_set_error("cv_stitch_ring_flags: bad argument"); return CV_ERR_INVALID; }
+    hipLaunchKernelGGL(k_ring_flags, dim3((n + 63) / 64), dim3(64), 0, st, ct_off, ct_xy, n, flags);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cva_set_error("cv_stitch_ring_flags: %s", hipGetErrorString(e)); return CV_ERR_HIP; }
+    return CV_OK;
+}
+
+// `Polygon.buffer(0)` -> largest part (cell_detection.py:689-704) on lattice rings — HOST code.  A ring whose lattice chain (every
+// lattice point along its edges; edges of a traced border run along the 8 lattice directions) visits a point twice is cut into
+// loops at the repeated points — the path between the two visits is a closed loop, what remains closes through the ring's first
+// point — and replaced by the loop of the largest |area| (the first such loop closed along the ring when areas tie; zero-width
+// spurs are loops of area 0 and vanish).  flags (u8 [n], from cv_stitch_ring_flags) limits the work to the flagged rings; NULL =
+// examine every ring.  out_off i64 [n+1] / out_xy i32 [>= ct_off[n], 2]: all rings, repaired ones with collinear points removed
+// (a lobe never has more vertices than its ring).  Edges that do not run along a lattice direction are kept as they are.
+namespace {
+struct Pt { int32_t x, y; };
+inline bool pt_eq(const Pt& a, const Pt& b) { return a.x == b.x && a.y == b.y; }
+
+bool largest_lobe(const int32_t* p, int m, std::vector<Pt>& chain, std::vector<Pt>& best) {
+    chain.clear();
+    for (int k = 0; k < m; ++k) {
+        const int k1 = k + 1 == m ? 0 : k + 1;
+        const int x0 = p[2 * k], y0 = p[2 * k + 1], dx = p[2 * k1] - x0, dy = p[2 * k1 + 1] - y0;
+        const int steps = std::max(std::abs(dx), std::abs(dy));
+        if (steps == 0) continue;
+        if (!(dx == 0 || dy == 0 || std::abs(dx) == std::abs(dy))) { chain.push_back({x0, y0}); continue; }
+        const int sx = (dx > 0) - (dx < 0), sy = (dy > 0) - (dy < 0);
+        for (int t = 0; t < steps; ++t) chain.push_back({x0 + t * sx, y0 + t * sy});
+    }
+    const int L = (int)chain.size();
+    // first-visit position of every lattice point on the current stack: sorted index of (x, y) -> slot
+    std::vector<int> order(L), slot_of(L), first(L, -1);
+    for (int i = 0; i < L; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        return chain[a].x != chain[b].x ? chain[a].x < chain[b].x : (chain[a].y != chain[b].y ? chain[a].y < chain[b].y : a < b);
+    });
+    bool repeated = false;
+    int ids = 0;
+    for (int r = 0; r < L; ++r) {
+        if (r > 0 && pt_eq(chain[order[r]], chain[order[r - 1]])) { slot_of[order[r]] = slot_of[order[r - 1]]; repeated = true; }
+        else slot_of[order[r]] = ids++;
+    }
+    if (!repeated) return false;
+    std::vector<int> stack;            // chain indices
+    std::vector<Pt> loop;
+    long long best_a = -1;
+    best.clear();
+    auto consider = [&](const std::vector<Pt>& lp) {
+        long long s2 = 0;
+        const int c = (int)lp.size();
+        if (c >= 3)
+            for (int k = 0; k < c; ++k) { const Pt& a = lp[k]; const Pt& b = lp[k + 1 == c ? 0 : k + 1]; s2 += (long long)a.x * b.y - (long long)b.x * a.y; }
+        if (s2 < 0) s2 = -s2;
+        if (s2 > best_a) { best_a = s2; best = lp; }
+    };
+    for (int i = 0; i < L; ++i) {
+        const int id = slot_of[i];
+        if (first[id] >= 0) {
+            const int k = first[id];
+            loop.clear();
+            for (int q = k; q < (int)stack.size(); ++q) loop.push_back(chain[stack[q]]);
+            for (int q = k + 1; q < (int)stack.size(); ++q) first[slot_of[stack[q]]] = -1;
+            stack.resize(k + 1);
+            consider(loop);
+        } else {
+            first[id] = (int)stack.size();
+            stack.push_back(i);
+        }
+    }
+    loop.clear();
+    for (int q : stack) loop.push_back(chain[q]);
+    consider(loop);
+    // remove collinear points of the winning loop (keep direction changes)
+    std::vector<Pt> simp;
+    const int c = (int)best.size();
+    for (int k = 0; k < c; ++k) {
+        const Pt& a = best[(k + c - 1) % c]; const Pt& b = best[k]; const Pt& d = best[(k + 1) % c];
+        const long long cr = (long long)(b.x - a.x) * (d.y - b.y) - (long long)(b.y - a.y) * (d.x - b.x);
+        const long long dt = (long long)(b.x - a.x) * (d.x - b.x) + (long long)(b.y - a.y) * (d.y - b.y);
+        if (cr != 0 || dt < 0) simp.push_back(b);
+    }
+    best.swap(simp);
+    return true;
+}
+}  // namespace
+
+extern "C" int cv_stitch_repair_rings(const int64_t* ct_off, const int32_t* ct_xy, int n, const uint8_t* flags, int64_t* out_off,
+                                      int32_t* out_xy, int32_t* n_repaired) {
+    if (n < 0 || (n && (!ct_off || !ct_xy || !out_off || !out_xy))) { cva_set_error("cv_stitch_repair_rings: bad argument"); return CV_ERR_INVALID; }
+    std::vector<Pt> chain, best;
+    int64_t w = 0;
+    int rep = 0;
+    if (out_off) out_off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t o = ct_off[i];
+        const int m = (int)(ct_off[i + 1] - o);
+        const int32_t* p = ct_xy + 2 * o;
+        if (m >= 3 && (!flags || flags[i]) && largest_lobe(p, m, chain, best)) {
+            if ((int)best.size() > m) { cva_set_error("cv_stitch_repair_rings: lobe of ring %d has %d vertices, the ring %d", i, (int)best.size(), m); return CV_ERR_SHAPE; }
+            for (const Pt& q : best) { out_xy[2 * w] = q.x; out_xy[2 * w + 1] = q.y; ++w; }
+            ++rep;
+        } else {
+            for (int k = 0; k < 2 * m; ++k) out_xy[2 * w + k] = p[k];
+            w += m;
+        }
+        out_off[i + 1] = w;
+    }
+    if (n_repaired) *n_repaired = rep;
+    return CV_OK;
+}
+
 // The greedy rounds of CellPostProcessor._remove_overlap (cell_detection.py:676-767) over a pair list: pure host code.
 //   pairs [n_pairs, 2] (i, j), overlap[k] != 0 when the pair overlaps by more than 1 % of either area, area [n], alive [n] in/out.
 // Per round, cells are visited in index order; a visited cell i collects its not-yet-visited live overlap partners (in index
-// order), marks them visited, and the round keeps the LARGEST of them (ties: the larger index, as max() over (area, index)
-// tuples) — or i itself when it has none.  Stops after a round without overlaps or after max_rounds.
+// order), marks them visited, and the round keeps the LARGEST of them (ties: the FIRST of equal areas in that order, as np.argmax
+// over the submerger list, cell_detection.py:743-746) — or i itself when it has none.  Stops after a round without overlaps or
+// after max_rounds.
 extern "C" int cv_stitch_select(const int32_t* pairs, const uint8_t* overlap, int n_pairs, const double* area, uint8_t* alive,
                                 int n, int max_rounds, int32_t* rounds_out, int32_t* overlaps_out) {
     if (n < 0 || n_pairs < 0 || (n_pairs && (!pairs || !overlap)) || (n && (!area || !alive))) { cva_set_error("cv_stitch_select: bad argument"); return CV_ERR_INVALID; }
@@ -283,7 +445,7 @@ extern "C" int cv_stitch_select(const int32_t* pairs, const uint8_t* overlap, in
                 if (!alive[j] || done[j]) continue;
                 ++overlaps;
                 done[j] = 1;
-                if (best < 0 || area[j] > area[best] || (area[j] == area[best] && j > best)) best = j;
+                if (best < 0 || area[j] > area[best]) best = j;
             }
             next[best >= 0 ? best : i] = 1;
             done[i] = 1;

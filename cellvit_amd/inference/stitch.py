@@ -172,8 +172,32 @@ def candidate_pairs_host(bbox: np.ndarray) -> np.ndarray:
     return p.astype(np.int32)
 
 
+def repair_rings(off: np.ndarray, ctg: np.ndarray, flags: Optional[np.ndarray] = None):
+    """`if not poly.is_valid: poly.buffer(0)` -> the part of the largest area (cell_detection.py:689-704) on the packed contour
+    arrays: rings whose lattice chain visits a lattice point twice (a blob pinched at a diagonal, a one-pixel spur) are replaced
+    by their largest simple lobe — host code of the library (`cv_stitch_repair_rings`).  `flags` (u8 [n], from the device
+    kernel `cv_stitch_ring_flags`) limits the work to the rings it names; None = every ring is examined.
+    Returns (off, ctg, number of repaired rings); the inputs themselves when nothing was repaired."""
+    n = len(off) - 1
+    if n <= 0 or (flags is not None and not flags.any()):
+        return off, ctg, 0
+    lib = _lib.load()
+    off_c = np.ascontiguousarray(off, np.int64)
+    ct_c = np.ascontiguousarray(ctg, np.int32).reshape(-1, 2)
+    out_off = np.empty(n + 1, np.int64)
+    out_ct = np.empty((max(1, len(ct_c)), 2), np.int32)
+    fl = None if flags is None else np.ascontiguousarray(flags, np.uint8)
+    nrep = C.c_int32(0)
+    _lib.check(lib.cv_stitch_repair_rings(off_c.ctypes.data, ct_c.ctypes.data, n, fl.ctypes.data if fl is not None else None,
+                                          out_off.ctypes.data, out_ct.ctypes.data, C.byref(nrep)))
+    if nrep.value == 0:
+        return off, ctg, 0
+    return out_off, out_ct[:int(out_off[-1])], int(nrep.value)
+
+
 def overlaps_host(bbox: np.ndarray, off: np.ndarray, ctg: np.ndarray):
-    """(pairs, inter, area) as `cv_stitch_overlaps`, on the host with the numpy routines above."""
+    """(pairs, inter, area) as `cv_stitch_overlaps`, on the host with the numpy routines above (rings repaired first)."""
+    off, ctg, _ = repair_rings(off, ctg)
     pairs = candidate_pairs_host(bbox)
     n = len(bbox)
     area = np.array([poly_area(ctg[off[i]:off[i + 1]]) for i in range(n)], np.float64)
@@ -191,19 +215,38 @@ def overlaps_device(bbox: np.ndarray, off: np.ndarray, ctg: np.ndarray, device: 
     lib = _lib.load()
     cap = int(cap or max(1024, 16 * n))
     with torch.cuda.device(device):
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+        def upload(off_, ctg_):
+            d_off_ = torch.from_numpy(np.ascontiguousarray(off_, np.int64)).to(device)
+            d_ct_ = torch.from_numpy(np.ascontiguousarray(ctg_, np.int32).reshape(-1, 2)).to(device)
+            if d_ct_.numel() == 0:
+                d_ct_ = torch.zeros((1, 2), dtype=torch.int32, device=device)
+            return d_off_, d_ct_
+
         d_bbox = torch.from_numpy(np.ascontiguousarray(bbox, np.int32)).to(device)
-        d_off = torch.from_numpy(np.ascontiguousarray(off, np.int64)).to(device)
-        d_ct = torch.from_numpy(np.ascontiguousarray(ctg, np.int32).reshape(-1, 2)).to(device)
-        if d_ct.numel() == 0:
-            d_ct = torch.zeros((1, 2), dtype=torch.int32, device=device)
-        d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=device)
-        d_inter = torch.empty((cap,), dtype=torch.float64, device=device)
+        d_off, d_ct = upload(off, ctg)
+        # invalid rings (cell_detection.py:689-704): found on the device, repaired (a handful per slide) by the library's host code
+        d_flags = torch.empty((n,), dtype=torch.uint8, device=device)
+        _lib.check(lib.cv_stitch_ring_flags(d_off.data_ptr(), d_ct.data_ptr(), n, d_flags.data_ptr(), stream))
+        flags = d_flags.cpu().numpy()
+        if flags.any():
+            off, ctg, nrep = repair_rings(off, ctg, flags)
+            if nrep:
+                d_off, d_ct = upload(off, ctg)
         d_area = torch.empty((n,), dtype=torch.float64, device=device)
         extent = (C.c_int32 * 4)(int(bbox[:, 0].min()), int(bbox[:, 1].min()), int(bbox[:, 2].max()), int(bbox[:, 3].max()))
         npairs = C.c_int32(0)
-        _lib.check(lib.cv_stitch_overlaps(d_bbox.data_ptr(), d_off.data_ptr(), d_ct.data_ptr(), n, extent, d_pairs.data_ptr(),
-                                          d_inter.data_ptr(), d_area.data_ptr(), cap, C.byref(npairs),
-                                          C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+        for attempt in range(2):      # a capacity overflow returns the exact pair count: retry once with it (never lose the slide)
+            d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=device)
+            d_inter = torch.empty((cap,), dtype=torch.float64, device=device)
+            rc = lib.cv_stitch_overlaps(d_bbox.data_ptr(), d_off.data_ptr(), d_ct.data_ptr(), n, extent, d_pairs.data_ptr(),
+                                        d_inter.data_ptr(), d_area.data_ptr(), cap, C.byref(npairs), stream)
+            if rc == _lib.CV_ERR_SHAPE and attempt == 0 and int(npairs.value) > cap:
+                cap = int(npairs.value)
+                continue
+            _lib.check(rc)
+            break
         p = int(npairs.value)
         pairs = d_pairs[:p].cpu().numpy()
         inter = d_inter[:p].cpu().numpy()

@@ -236,12 +236,21 @@ int cv_pp_records(cv_pp* pp, int32_t* inst_map, const uint8_t* type_map, int B, 
  * HOST i32 [4] (min row, min col, max row, max col over all boxes).  Outputs: pairs i32 [cap,2] = candidate pairs (i < j) whose
  * boxes overlap strictly (order unspecified), inter f64 [cap] = EXACT area of the intersection of the two contour polygons
  * (even-odd interiors; -1 where a fixed per-thread capacity was exceeded: evaluate that pair on the host), area f64 [n] = polygon
- * areas.  Synchronises the stream (the pair count is returned to the host); CV_ERR_SHAPE when more than cap pairs exist.        */
+ * areas.  Synchronises the stream (the pair count is returned to the host); CV_ERR_SHAPE when more than cap pairs exist —
+ * n_pairs_host then holds the required capacity.                                                                                 */
 int cv_stitch_overlaps(const int32_t* bbox, const int64_t* ct_off, const int32_t* ct_xy, int n, const int32_t* extent,
                        int32_t* pairs, double* inter, double* area, int cap, int32_t* n_pairs_host, void* stream);
+/* Invalid (self-touching) contour rings of the same function (:689-704: `if not poly.is_valid` -> `poly.buffer(0)` -> the part of the
+ * largest area).  cv_stitch_ring_flags — DEVICE pointers: flags u8 [n] = 1 where ring i (ct_off / ct_xy as above) is not simple
+ * (two non-adjacent edges share a point, consecutive edges fold back, a vertex repeats).  cv_stitch_repair_rings — HOST pointers,
+ * host code: the rings with flags[i] != 0 (flags NULL: every ring is examined) whose lattice chain visits a lattice point twice
+ * are replaced by their largest simple lobe; out_off i64 [n+1], out_xy i32 [ct_off[n], 2] receive all rings; n_repaired may be NULL. */
+int cv_stitch_ring_flags(const int64_t* ct_off, const int32_t* ct_xy, int n, uint8_t* flags, void* stream);
+int cv_stitch_repair_rings(const int64_t* ct_off, const int32_t* ct_xy, int n, const uint8_t* flags, int64_t* out_off,
+                           int32_t* out_xy, int32_t* n_repaired);
 /* The greedy rounds of the same function (:706-767) over a pair list — HOST pointers, host code: per round cells are visited in
- * index order, a visited cell collects its live, not yet visited overlap partners and the largest of them survives in its place
- * (the cell itself when it has none); stops after a round without overlaps or max_rounds (reference: 20).  overlap[k] != 0 marks
+ * index order, a visited cell collects its live, not yet visited overlap partners and the largest of them (the first of equal
+ * areas, np.argmax :743-746) survives in its place (the cell itself when it has none); stops after a round without overlaps or max_rounds (reference: 20).  overlap[k] != 0 marks
  * pairs overlapping by more than 1 % of either area; alive u8 [n] in/out; overlaps_out i32 [max_rounds] per-round counts.       */
 int cv_stitch_select(const int32_t* pairs, const uint8_t* overlap, int n_pairs, const double* area, uint8_t* alive, int n,
                      int max_rounds, int32_t* rounds_out, int32_t* overlaps_out);

@@ -19,6 +19,8 @@ CASES = {
     "vit256_1024": (lambda: cellvit256_config(), 1, 1024, 1024),          # BASELINE.json configs[1] geometry (4097 tokens)
     "vit256_nohead_64": (lambda: cellvit256_config(6, 0), 2, 64, 64),     # num_tissue_classes = 0: head = nn.Identity
     "samb_nohead_64": (lambda: cellvit_sam_config("SAM-B", 6, 0), 2, 64, 64),
+    "vit256_reg_64": (lambda: cellvit256_config(6, 19, True), 2, 64, 64),    # regression_loss=True (cellvit.py:191-196)
+    "samb_reg_64": (lambda: cellvit_sam_config("SAM-B", 6, 19, True), 2, 64, 64),
 }
 
 

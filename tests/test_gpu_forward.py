@@ -19,10 +19,11 @@ def _model(cfg, sd, dtype):
     from cellvit_amd.model import CellViT256, CellViTSAM
     from cellvit_amd.spec import ARCH_VIT
     if cfg.arch == ARCH_VIT:
-        m = CellViT256(None, cfg.num_nuclei_classes, cfg.num_tissue_classes, compute_dtype=dtype)
+        m = CellViT256(None, cfg.num_nuclei_classes, cfg.num_tissue_classes, regression_loss=cfg.regression_loss, compute_dtype=dtype)
     else:
         name = {768: "SAM-B", 1024: "SAM-L", 1280: "SAM-H"}[cfg.embed_dim]
-        m = CellViTSAM(None, cfg.num_nuclei_classes, cfg.num_tissue_classes, name, compute_dtype=dtype)
+        m = CellViTSAM(None, cfg.num_nuclei_classes, cfg.num_tissue_classes, name, regression_loss=cfg.regression_loss,
+                       compute_dtype=dtype)
     m.load_state_dict(sd)
     return m
 
@@ -89,6 +90,31 @@ def test_forward_fp16_error_statistics(name):
         assert stats[k][0] < ATOL_F16, (k, stats[k])
     assert stats["nuclei_binary_map_argmax_agree"] >= ARGMAX_BIN
     assert stats["nuclei_type_map_argmax_agree"] >= ARGMAX_TYPE
+
+
+@pytest.mark.parametrize("name", ["vit256_reg_64", "samb_reg_64"])
+def test_forward_regression_loss_branch_matches_reference_golden(name):
+    """regression_loss=True (cellvit.py:191-196, 623-630): the binary branch's head has 4 output channels; `nuclei_binary_map` is
+    channels 0-1, `regression_map` channels 2-3.  fp32 engine <= 1e-3 against the imported reference on every output incl. the
+    regression map; fp16 engine within the fp16 bound, argmax planes == argmax of the two binary channels."""
+    cfg, sd, x, gold = load_case(name)
+    assert cfg.regression_loss and gold["regression_map"].shape == (x.shape[0], 2, x.shape[2], x.shape[3])
+    keys = ("tissue_types", "nuclei_binary_map", "hv_map", "nuclei_type_map", "tokens", "regression_map")
+    m = _model(cfg, sd, "fp32")
+    out = m(x.cuda(), retrieve_tokens=True)
+    torch.cuda.synchronize()
+    assert list(out.keys())[:3] == ["tissue_types", "nuclei_binary_map", "regression_map"]        # the reference's dict order
+    errs = compare_outputs(out, gold, atol=ATOL_F32, keys=keys)
+    print(f"\n[{name} fp32] output max abs err: {errs}")
+    m16 = _model(cfg, sd, "fp16")
+    o16 = m16(x.cuda(), retrieve_tokens=True)
+    torch.cuda.synchronize()
+    for k in ("nuclei_binary_map", "regression_map", "hv_map", "nuclei_type_map"):
+        e = float(np.abs(o16[k].float().cpu().numpy() - gold[k]).max())
+        print(f"[{name} fp16] {k}: max abs err {e:.3e}")
+        assert e < ATOL_F16, (k, e)
+    inst = m16.calculate_instance_map(o16, magnification=40)[0]      # the product route consumes the 2-channel argmax plane
+    assert inst.shape[0] == x.shape[0]
 
 
 def test_forward_fp32_samh_1024_crops():

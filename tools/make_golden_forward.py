@@ -40,7 +40,9 @@ def run(name, model, cfg, batch, h, w, full=True, crop=64, tok_crop=None):
         out = model(x, retrieve_tokens=True)
     print(f"  reference forward {time.time() - t:.1f}s")
     rec = {"meta_shape": np.array([batch, h, w]), "tissue_types": out["tissue_types"].numpy()}
-    for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map", "tokens"):
+    for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map", "tokens", "regression_map"):
+        if k not in out:
+            continue
         v = out[k].numpy()
         if full:
             rec[k] = v
@@ -61,7 +63,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     cv = ref_import.import_cellvit()
     which = sys.argv[1:] or ["vit256_256", "vit256_b2_128x192", "samb_128", "samh_256", "samh_1024", "vit256_1024",
-                             "vit256_nohead_64", "samb_nohead_64"]
+                             "vit256_nohead_64", "samb_nohead_64", "vit256_reg_64", "samb_reg_64"]
     if "vit256_256" in which:   # BASELINE.json configs[0]
         run("vit256_256", cv.CellViT256(None, 6, 19), cellvit256_config(), 1, 256, 256)
     if "vit256_b2_128x192" in which:   # batch > 1, non-square (bicubic pos-embed w/h handling)
@@ -79,6 +81,10 @@ def main():
         run("vit256_nohead_64", cv.CellViT256(None, 6, 0), cellvit256_config(6, 0), 2, 64, 64)
     if "samb_nohead_64" in which:     # num_tissue_classes = 0: tissue_types = mean of the neck output
         run("samb_nohead_64", cv.CellViTSAM(None, 6, 0, "SAM-B"), cellvit_sam_config("SAM-B", 6, 0), 2, 64, 64)
+    if "vit256_reg_64" in which:      # regression_loss=True: binary branch has 4 channels, split 2 + 2 (cellvit.py:191-196)
+        run("vit256_reg_64", cv.CellViT256(None, 6, 19, regression_loss=True), cellvit256_config(6, 19, True), 2, 64, 64)
+    if "samb_reg_64" in which:        # the same through CellViTSAM.forward (cellvit.py:623-630)
+        run("samb_reg_64", cv.CellViTSAM(None, 6, 19, "SAM-B", regression_loss=True), cellvit_sam_config("SAM-B", 6, 19, True), 2, 64, 64)
 
 
 if __name__ == "__main__":
