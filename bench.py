@@ -319,14 +319,21 @@ def main():
     for _ in range(args.steps):
         out, res = step()
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0           # this rank's own clock for its K steps
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # per-rank clocks as well: each rank's own time for its K steps (before the closing barrier), gathered to rank 0
+    per_rank_tiles_per_s, backend = [B * args.steps / dt_rank], None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        own = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(own, torch.tensor([dt_rank], device=dev, dtype=torch.float64))
+        per_rank_tiles_per_s = [B * args.steps / float(o.item()) for o in own]
+        backend = dist.get_backend()
 
     if rank == 0:
         n_inst = int(res[2].sum().item()) if res is not None else 0
@@ -367,6 +374,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "tile": T, "tiles_per_step_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"tile-sharded x{world}, no data-path collective",
+                       "ranks": world, "collective_backend": backend, "per_rank_tiles_per_s": [round(v, 2) for v in per_rank_tiles_per_s],
                        "input": "raw uint8 HWC tiles resident in HBM; inference transform fused into the forward (cv_forward_u8)",
                        "experiment_env": dbg + (["ABLATION_BUILD"] if _lib.load().cv_build_is_ablation() else []),
                        "library": os.path.relpath(_lib.LIB_PATH, ROOT), "library_build_flags": (_lib.load().cv_build_flags() or b"").decode(),

@@ -1512,7 +1512,7 @@ extern "C" int cv_pp_run_params(cv_pp* p, const uint8_t* bin, const uint8_t* typ
                                 int32_t* n_recs, int32_t* contours, int32_t* n_pts, void* stream) {
     if (!p || !bin || !hv || !inst_map || !recs || !n_recs || !n_pts) { cva_set_error("null argument"); return CV_ERR_INVALID; }
     if (ksize != 21 && ksize != 11) { cva_set_error("Sobel ksize must be 21 or 11"); return CV_ERR_INVALID; }
-    if (nr_types < 0 || nr_types > 8 || (nr_types > 0 && !type)) { cva_set_error("nr_types must be in [0, 8]"); return CV_ERR_INVALID; }
+    if (nr_types < 0 || nr_types > 256 || (nr_types > 0 && !type)) { cva_set_error("nr_types must be in [0, 256]"); return CV_ERR_INVALID; }
     if (B <= 0 || B > p->d.B) { cva_set_error("batch %d exceeds the handle's max_batch %d", B, p->d.B); return CV_ERR_INVALID; }
     const int rc = pp_run(p->ws, bin, type, hv, B, object_size, ksize, nr_types, inst_map, reinterpret_cast<InstanceRec*>(recs),
                           n_recs, contours, n_pts, reinterpret_cast<hipStream_t>(stream));
@@ -1534,7 +1534,7 @@ extern "C" int cv_pp_run(cv_pp* p, const uint8_t* bin, const uint8_t* type, cons
 extern "C" int cv_pp_records(cv_pp* p, int32_t* inst_map, const uint8_t* type, int B, int nr_types, cv_instance* recs,
                              int32_t* n_recs, int32_t* contours, int32_t* n_pts, void* stream) {
     if (!p || !inst_map || !recs || !n_recs || !n_pts) { cva_set_error("null argument"); return CV_ERR_INVALID; }
-    if (nr_types < 0 || nr_types > 8 || (nr_types > 0 && !type)) { cva_set_error("nr_types must be in [0, 8]"); return CV_ERR_INVALID; }
+    if (nr_types < 0 || nr_types > 256 || (nr_types > 0 && !type)) { cva_set_error("nr_types must be in [0, 256]"); return CV_ERR_INVALID; }
     if (B <= 0 || B > p->d.B) { cva_set_error("batch %d exceeds the handle's max_batch %d", B, p->d.B); return CV_ERR_INVALID; }
     const int rc = pp_records(p->ws, inst_map, type, B, nr_types, reinterpret_cast<InstanceRec*>(recs), n_recs, contours, n_pts,
                               reinterpret_cast<hipStream_t>(stream));

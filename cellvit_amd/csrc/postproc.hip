@@ -796,6 +796,79 @@ __global__ void k_inst_records(StatArrays st, InstanceRec* __restrict__ recs, in
     }
 }
 
+// ---- type vote for MORE than 8 classes (post_proc_cellvit.py:132-148 / :300-318: np.unique counts, sorted by count descending —
+// a stable sort, so equal counts keep ascending type order — background replaced by the runner-up).  The 8-bin histogram of
+// k_inst_stats is filled once per window of 8 types [t_lo, t_lo + 8), and a running (best, second, number of present types) per
+// id is merged window by window in ascending type order: `>` keeps the LOWER type on equal counts, as the stable sort does.
+struct VoteArrays { int* best_t; unsigned* best_c; int* second_t; unsigned* second_c; int* present; };
+
+__global__ void k_vote_reset(VoteArrays v, unsigned* __restrict__ hist, const int* __restrict__ nmark, int max_ids, int first_window) {
+    const int tile = blockIdx.y;
+    const long sb = (long)tile * (max_ids + 1);
+    const int hi = min(max_ids, nmark[tile]);
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id <= hi; id += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hist[(sb + id) * 8 + k] = 0u;
+        if (first_window) { v.best_t[sb + id] = -1; v.best_c[sb + id] = 0u; v.second_t[sb + id] = -1; v.second_c[sb + id] = 0u; v.present[sb + id] = 0; }
+    }
+}
+
+// per horizontal run of an instance (as k_inst_stats): counts of the types inside the window
+__global__ void k_type_hist_window(const int* __restrict__ inst, const uint8_t* __restrict__ type, unsigned* __restrict__ hist,
+                                   int H, int W, int max_ids, int t_lo) {
+    const int N = H * W, tile = blockIdx.y;
+    const long base = (long)tile * N, sb = (long)tile * (max_ids + 1);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int id = inst[base + i];
+        if (id <= 0 || id > max_ids) continue;
+        const int x = i % W;
+        if (x > 0 && inst[base + i - 1] == id) continue;
+        int len = 0;
+        unsigned h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        do {
+            const int t = (int)type[base + i + len] - t_lo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) h[k] += (t == k);
+            ++len;
+        } while (x + len < W && inst[base + i + len] == id);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (h[k]) atomicAdd(&hist[(sb + id) * 8 + k], h[k]);
+    }
+}
+
+__global__ void k_vote_merge(VoteArrays v, const unsigned* __restrict__ hist, const int* __restrict__ nmark, int max_ids, int t_lo, int nr_types) {
+    const int tile = blockIdx.y;
+    const long sb = (long)tile * (max_ids + 1);
+    const int hi = min(max_ids, nmark[tile]);
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id <= hi; id += gridDim.x * blockDim.x) {
+        int bt = v.best_t[sb + id], st_ = v.second_t[sb + id], pr = v.present[sb + id];
+        unsigned bc = v.best_c[sb + id], sc = v.second_c[sb + id];
+        for (int k = 0; k < 8 && t_lo + k < nr_types; ++k) {
+            const unsigned c = hist[(sb + id) * 8 + k];
+            if (!c) continue;
+            ++pr;
+            if (c > bc) { st_ = bt; sc = bc; bt = t_lo + k; bc = c; }
+            else if (c > sc) { st_ = t_lo + k; sc = c; }
+        }
+        v.best_t[sb + id] = bt; v.best_c[sb + id] = bc; v.second_t[sb + id] = st_; v.second_c[sb + id] = sc; v.present[sb + id] = pr;
+    }
+}
+
+__global__ void k_vote_apply(VoteArrays v, InstanceRec* __restrict__ recs, const int* __restrict__ n_recs, int max_ids, int max_inst) {
+    const int tile = blockIdx.y;
+    const long sb = (long)tile * (max_ids + 1);
+    const int nr = min(n_recs[tile], max_inst);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nr; k += gridDim.x * blockDim.x) {
+        InstanceRec* r = &recs[(long)tile * max_inst + k];
+        const int id = r->id;
+        int ty = v.best_t[sb + id];
+        unsigned c = v.best_c[sb + id];
+        if (ty == 0 && v.present[sb + id] > 1) { ty = v.second_t[sb + id]; c = v.second_c[sb + id]; }
+        r->type = ty < 0 ? 0 : ty;
+        r->type_prob = (double)c / ((double)r->npix + 1.0e-6);
+    }
+}
+
 // Suzuki-Abe outer border + CHAIN_APPROX_SIMPLE (OpenCV icvFetchContour), see oracle trace_contour
 __device__ int trace_contour(const int* __restrict__ inst, int H, int W, int id, int x0, int y0, int* __restrict__ pts) {
     const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
@@ -897,8 +970,35 @@ struct PostprocWorkspace {
     unsigned long long* ovf_lo = nullptr; int* ovf_lab = nullptr;
     unsigned long long* ovf_cursor = nullptr;
     StatArrays st{};
+    VoteArrays vote{};               // allocated on the first call with more than 8 nucleus classes
     int list_cap = 0, nblk = 0;
 };
+
+// type vote over windows of 8 classes (nr_types > 8): overrides the type / type_prob fields k_inst_records wrote
+static int vote_wide(PostprocWorkspace* w, const int32_t* inst, const uint8_t* type, int B, int nr_types, InstanceRec* recs,
+                     const int32_t* n_recs, const int* nmark, hipStream_t st) {
+    const PostprocDims& d = w->d;
+    const size_t S = (size_t)d.B * (size_t)(d.max_ids + 1);
+    if (!w->vote.best_t) {
+        void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < 5; ++k) {
+            if (hipMalloc(&p[k], S * 4) != hipSuccess) return 1;
+            w->pool.push_back(p[k]); w->bytes += S * 4;
+        }
+        w->vote.best_t = (int*)p[0]; w->vote.best_c = (unsigned*)p[1]; w->vote.second_t = (int*)p[2]; w->vote.second_c = (unsigned*)p[3];
+        w->vote.present = (int*)p[4];
+    }
+    const int H = d.H, W = d.W, N = H * W;
+    const dim3 grid(std::min((N + NT - 1) / NT, 2048), B), blk(NT), igrid(std::min((d.max_ids + NT) / NT, 32), B);
+    for (int t_lo = 0; t_lo < nr_types; t_lo += 8) {
+        hipLaunchKernelGGL(k_vote_reset, igrid, blk, 0, st, w->vote, w->st.hist, nmark, d.max_ids, t_lo == 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_type_hist_window, grid, blk, 0, st, inst, type, w->st.hist, H, W, d.max_ids, t_lo);
+        hipLaunchKernelGGL(k_vote_merge, igrid, blk, 0, st, w->vote, w->st.hist, nmark, d.max_ids, t_lo, nr_types);
+    }
+    const dim3 cgrid((d.max_inst + NT - 1) / NT > 64 ? 64 : (d.max_inst + NT - 1) / NT, B);
+    hipLaunchKernelGGL(k_vote_apply, cgrid, blk, 0, st, w->vote, recs, n_recs, d.max_ids, d.max_inst);
+    return 0;
+}
 
 int pp_workspace_create(const PostprocDims& d, PostprocWorkspace** out) {
     PostprocWorkspace* w = new PostprocWorkspace();
@@ -1012,6 +1112,7 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     // ---- P7/P8: per-instance records + contours ----
     hipLaunchKernelGGL(k_inst_stats, grid, blk, 0, st, inst_out, type, w->st, H, W, d.max_ids, nr_types);
     hipLaunchKernelGGL(k_inst_records, dim3(B), blk, 0, st, w->st, recs, n_recs, d.max_ids, d.max_inst, nr_types, nmark);
+    if (nr_types > 8 && vote_wide(w, inst_out, type, B, nr_types, recs, n_recs, nmark, st)) return 1;
     const dim3 cgrid((d.max_inst + 63) / 64 > 64 ? 64 : (d.max_inst + 63) / 64, B);
     hipLaunchKernelGGL(k_contour_count, cgrid, dim3(64), 0, st, inst_out, recs, n_recs, H, W, d.max_inst);
     hipLaunchKernelGGL(k_contour_offsets, dim3(B), blk, 0, st, recs, n_recs, n_pts, d.max_inst);
@@ -1039,6 +1140,7 @@ int pp_records(PostprocWorkspace* w, int32_t* inst_io, const uint8_t* type, int 
     hipLaunchKernelGGL(k_stats_init, dim3(std::min((d.max_ids + NT) / NT, 32), B), blk, 0, st, w->st, w->msize, nmark, d.max_ids);
     hipLaunchKernelGGL(k_inst_stats, grid, blk, 0, st, inst_io, type, w->st, H, W, d.max_ids, nr_types);
     hipLaunchKernelGGL(k_inst_records, dim3(B), blk, 0, st, w->st, recs, n_recs, d.max_ids, d.max_inst, nr_types, nmark);
+    if (nr_types > 8 && vote_wide(w, inst_io, type, B, nr_types, recs, n_recs, nmark, st)) return 1;
     const dim3 cgrid((d.max_inst + 63) / 64 > 64 ? 64 : (d.max_inst + 63) / 64, B);
     hipLaunchKernelGGL(k_contour_count, cgrid, dim3(64), 0, st, inst_io, recs, n_recs, H, W, d.max_inst);
     hipLaunchKernelGGL(k_contour_offsets, dim3(B), blk, 0, st, recs, n_recs, n_pts, d.max_inst);

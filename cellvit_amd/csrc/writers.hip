@@ -30,10 +30,13 @@ struct Out {
     void i64(long long v) { char t[24]; const int n = snprintf(t, sizeof t, "%lld", v); put(t, n); }
     void f64(double v) {
         char t[40];
+        // non-finite values as Python's json encoder writes them (NaN / Infinity / -Infinity: what json.load parses back)
+        if (v != v) { put("NaN"); return; }
+        if (v - v != 0.0) { put(v > 0 ? "Infinity" : "-Infinity"); return; }
         int n = snprintf(t, sizeof t, "%.17g", v);
         // JSON numbers as Python writes floats: always with a fraction or exponent ("3.0", not "3")
         bool plain = true;
-        for (int k = 0; k < n; ++k) if (t[k] == '.' || t[k] == 'e' || t[k] == 'n' || t[k] == 'i') { plain = false; break; }
+        for (int k = 0; k < n; ++k) if (t[k] == '.' || t[k] == 'e') { plain = false; break; }
         if (plain) { t[n++] = '.'; t[n++] = '0'; }
         put(t, n);
     }
@@ -98,7 +101,8 @@ extern "C" int cv_write_cells_json(const char* path, const char* header, int det
     }
     o.put(n ? "\n]}" : "]}");
     o.flush();
-    const bool ok = o.ok && fclose(f) == 0;
+    const bool closed = fclose(f) == 0;          // always closed, also after a failed write
+    const bool ok = o.ok && closed;
     if (!ok) { cva_set_error("cv_write_cells_json: write to %s failed", path); return CV_ERR_INVALID; }
     return CV_OK;
 }

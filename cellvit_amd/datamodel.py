@@ -156,7 +156,7 @@ def save_cell_graph(path, x: torch.Tensor, positions: torch.Tensor, contour_poin
         graph = make_cell_graph(x=x, positions=positions, contours=[pts], metadata=metadata)
         torch.save(graph, path, pickle_module=mod, pickle_protocol=2)
         return "fast"
-    except (ValueError, StopIteration):
+    except Exception:      # anything the byte-stream rewrite can trip over (another torch / pickle layout): the plain route always works
         graph = make_cell_graph(x=x, positions=positions, contours=list(pts.split(lens)), metadata=metadata)
         torch.save(graph, path)
         return "torch.save"

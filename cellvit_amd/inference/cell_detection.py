@@ -245,20 +245,24 @@ class SlideCells:
 
 def finalize_slide(local: SlideCells, patch_size: int, downsampling: float, overlap: int, device=None,
                    logger: Optional[logging.Logger] = None, compute_device=None,
-                   timings: Optional[dict] = None, want_dicts: bool = True) -> Tuple[SlideCells, Optional[List[dict]]]:
+                   timings: Optional[dict] = None, want_dicts: bool = True,
+                   gather_to: Optional[int] = None) -> Tuple[Optional[SlideCells], Optional[List[dict]]]:
     """Slide-level step after the tile loop (cell_detection.py:423-433), identical for any world size:
       1. every rank contributes ONLY its margin-cell records (status != 0) to one all-gatherv
          (`sharding.all_gather_margin_records`: RCCL over xGMI with device buffers, gloo on CPU);
       2. the gathered records are put in slide order (tile index) and ONE global de-duplication runs on the packed arrays
          (`stitch.stitch_margin_records`: candidate pairs + exact polygon intersections on the GPU, the greedy rounds in the
          library's host code) — the same deterministic computation on every rank, so no second collective is needed;
-      3. each rank keeps its mid cells + its surviving margin cells; the survivors of all ranks are then gathered
-         in slide order for the single writer (rank 0).
+      3. each rank keeps its mid cells + its surviving margin cells; the survivors of all ranks are then collected in slide
+         order: `gather_to=r` (what the CLI does, r = 0 = the one writer) sends every rank's kept cells and token rows to rank r
+         ONLY — point to point, exact sizes, nothing replicated: a rank's traffic is its own cells once (≈ 5 KB per cell with
+         1280-float tokens; the writer receives the slide's ≈ 3 GB once instead of every rank receiving it);
+         `gather_to=None` all-gathers them so that the result is complete on every rank (tests, callers that ask for it).
     Every collective is entered by every rank, whatever it holds (a rank may have received no tile at all).
     `device`: where the exchange buffers live (cuda under nccl, cpu under gloo); `compute_device`: where the geometry of the
     de-duplication runs (default: `device`).  `timings` (optional dict) receives the seconds of exchange / stitch / dicts.
     Returns (all kept cells of the slide in slide order, their dicts or None with want_dicts=False) — complete on every
-    rank.  Nothing on this path needs per-cell dicts: the writers render the files from the arrays (`write_outputs`)."""
+    rank, or on rank `gather_to` only ((None, None) elsewhere).  Nothing on this path needs per-cell dicts: the writers render the files from the arrays (`write_outputs`)."""
     import time
     import torch.distributed as dist
     from .stitch import stitch_margin_records
@@ -280,8 +284,30 @@ def finalize_slide(local: SlideCells, patch_size: int, downsampling: float, over
     uid = lambda ir: ir[:, S.I_TILE].astype(np.int64) * (1 << 32) + ir[:, S.I_ID].astype(np.int64)   # noqa: E731
     keep_local = np.nonzero(~is_margin | np.isin(uid(local.ir), uid(gi[keep_g])))[0].astype(np.int64)
     mine = local.select(keep_local)
-    if world > 1:
-        ai, af, ac = S.all_gather_margin_records(mine.ir, mine.fr, mine.ct, device=dev)   # the writer's gather (same packed format)
+    n_total = sum(S.all_gather_int(len(mine), dev)) if world > 1 else len(mine)
+    sent = recv = 0
+    if world > 1 and gather_to is not None:
+        # the writer's gather: kept cells + their token rows travel to ONE rank (only one writer exists, cell_detection.py:423-475);
+        # every rank sends exactly its own bytes — nothing is replicated
+        got, s_, r_ = S.gather_records_to(mine.ir, mine.fr, mine.ct, gather_to, device=dev)
+        sent += s_; recv += r_
+        D = max(S.all_gather_int(int(mine.tokens.shape[1]) if mine.tokens is not None else 0, dev))
+        tok = None
+        if D > 0:
+            t_loc = mine.tokens if mine.tokens is not None else torch.zeros((0, D), dtype=torch.float32)
+            tok, s_, r_ = S.gather_rows_to(t_loc.to(dev).float(), gather_to)
+            sent += s_; recv += r_
+        if got is not None:
+            ai, af, ac = got
+            perm = S.canonical_order(ai)
+            ai, af, ac = S.reorder_records(ai, af, ac, perm)
+            if tok is not None:
+                tok = tok[torch.as_tensor(perm, dtype=torch.long, device=tok.device)]
+            allc = SlideCells(ai, af, ac, tok)
+        else:
+            allc = None
+    elif world > 1:
+        ai, af, ac = S.all_gather_margin_records(mine.ir, mine.fr, mine.ct, device=dev)   # complete on every rank (tests, callers that ask)
         # token rows: the width is agreed first, ranks without cells contribute [0, D]
         D = max(S.all_gather_int(int(mine.tokens.shape[1]) if mine.tokens is not None else 0, dev))
         tok = None
@@ -297,11 +323,13 @@ def finalize_slide(local: SlideCells, patch_size: int, downsampling: float, over
         perm = S.canonical_order(mine.ir)
         allc = mine.select(perm)
     if logger:
-        logger.info(f"[rank {rank}] cells after cleaning: {len(allc)} (margin cells exchanged: {len(gi)})")
+        logger.info(f"[rank {rank}] cells after cleaning: {n_total} (margin cells exchanged: {len(gi)})")
     t_collect = time.perf_counter()
-    dicts = allc.to_dicts(patch_size, downsampling, overlap) if want_dicts else None
+    dicts = allc.to_dicts(patch_size, downsampling, overlap) if (want_dicts and allc is not None) else None
     if timings is not None:
-        timings.update({"margin_records": int(len(gi)), "margin_kept": int(len(keep_g)),
+        margin_bytes = int(gi.nbytes + gf.nbytes + gc.nbytes)
+        timings.update({"margin_records": int(len(gi)), "margin_kept": int(len(keep_g)), "n_cells_total": int(n_total),
+                        "margin_bytes_all_gathered": margin_bytes, "writer_gather_bytes_sent": int(sent), "writer_gather_bytes_received": int(recv),
                         "exchange_s": (t_gather - t_start) + (t_collect - t_stitch), "stitch_s": t_stitch - t_gather,
                         "to_dicts_s": time.perf_counter() - t_collect})
     return allc, dicts
@@ -416,6 +444,13 @@ class CellSegmentationInference:
                 else:
                     idx = torch.as_tensor(np.concatenate(rows) if rows else np.zeros(0, np.int64), dtype=torch.long, device=pooled.device)
                     tok = pooled.reshape(-1, pooled.shape[-1]).index_select(0, idx)
+                # cross-stream lifetimes for the caching allocator: `pooled` was allocated on the compute stream and is read here on
+                # the copy stream (the job is dropped right after); `tok` is allocated on the copy stream and read later by
+                # torch.cat / select on the compute stream
+                for t_ in (pooled if isinstance(pooled, list) else [pooled]):
+                    t_.record_stream(copy_stream)
+                if tok is not None:
+                    tok.record_stream(torch.cuda.current_stream(self.device))
             o = 0
             for ir, fr, ct, n in tiles_out:
                 parts.append(SlideCells(ir, fr, ct, tok[o:o + n]))
@@ -447,6 +482,21 @@ class CellSegmentationInference:
             if err is not None:
                 raise err
 
+    def _agree_on_writer_error(self, exch_dev) -> None:
+        import torch.distributed as dist
+        err = None
+        try:
+            self.wait_for_writers()
+        except BaseException as e:      # noqa: BLE001
+            err = e
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=exch_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and err is None:
+                raise RuntimeError("the writer of the previous slide failed on rank 0")
+        if err is not None:
+            raise err
+
     def process_wsi(self, wsi: PatchedSlide, subdir_name: Optional[str] = None, patch_size: int = 1024,
                     overlap: int = 64, batch_size: int = 8, geojson: bool = False, defer_write: bool = False) -> dict:
         """`defer_write`: hand the files of this slide to a writer thread and return (process_dataset: the files of slide k are
@@ -464,8 +514,12 @@ class CellSegmentationInference:
                          f"({stats['tiles'] / max(stats['t_loop'], 1e-9):.1f} tiles/s), cells before cleaning: {len(local)}")
         exch_dev = self.device if (dd and dist.get_backend() == "nccl") else torch.device("cpu")
         timings: dict = {}
+        # a writer failure of the PREVIOUS slide (rank 0 only) is agreed on by all ranks before this slide's first collective:
+        # everyone aborts together instead of the other ranks hanging in the next exchange
+        self._agree_on_writer_error(exch_dev)
         allc, _ = finalize_slide(local, wsi.metadata["patch_size"], wsi.metadata["downsampling"], overlap,
-                                 device=exch_dev, logger=self.logger, compute_device=self.device, timings=timings, want_dicts=False)
+                                 device=exch_dev, logger=self.logger, compute_device=self.device, timings=timings, want_dicts=False,
+                                 gather_to=0)
         if world > 1:
             gathered: List[Optional[list]] = [None] * world
             dist.all_gather_object(gathered, processed)       # tile names only (a few bytes per tile)
@@ -490,7 +544,8 @@ class CellSegmentationInference:
             else:
                 write_outputs(*wargs)
         timings["write_s"] = time.perf_counter() - t0
-        stats.update({"n_cells": len(allc), "cells_before_cleaning": len(local), "outdir": str(outdir), **timings})
+        stats.update({"n_cells": int(timings.get("n_cells_total", len(allc) if allc is not None else 0)),
+                      "cells_before_cleaning": len(local), "outdir": str(outdir), **timings})
         return stats
 
 

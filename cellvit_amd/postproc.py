@@ -248,8 +248,8 @@ def calculate_instances(pred_types: torch.Tensor, pred_insts: torch.Tensor) -> L
     B, H, W = pred_insts.shape
     typ = argmax_channels(pred_types.to(dev)) if pred_types.shape[1] > 1 else torch.zeros((B, H, W), device=dev, dtype=torch.uint8)
     nr_types = int(pred_types.shape[1])
-    if nr_types > 8:      # the type vote of k_inst_stats has 8 bins; the reference's np.unique has no limit (post_proc_cellvit.py:300-318)
-        raise NotImplementedError(f"calculate_instances: {nr_types} nucleus classes, the device type vote holds at most 8")
+    if nr_types > 256:    # u8 type planes; more than 8 classes vote in windows of 8 on the device (post_proc_cellvit.py:300-318: np.unique has no limit)
+        raise NotImplementedError(f"calculate_instances: {nr_types} nucleus classes, the type planes are uint8")
     e = _PPEngine.get(dev, B, H, W)
     if int(pred_insts.max()) > H * W // 16:
         raise CapacityError(f"instance ids above {H * W // 16} have no accumulator slot on a {H}x{W} tile: remap the labels first")

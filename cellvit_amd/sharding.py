@@ -146,6 +146,58 @@ def all_gather_margin_records(ir: np.ndarray, fr: np.ndarray, ct: np.ndarray, de
     return cat(parts_i), cat(parts_f), cat(parts_c)
 
 
+def _gather_var_to(t: torch.Tensor, dst: int, group=None):
+    """gatherv to ONE rank: the row counts travel in an all-gather of one integer per rank, the rows point to point — every
+    rank sends exactly its own bytes to `dst` and nothing is replicated (an all-gatherv pads every contribution to the largest
+    and delivers world x that to every rank).  Returns (list of per-rank tensors on `dst`, None elsewhere; bytes sent by this
+    rank; bytes received by this rank)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    t = t.contiguous()
+    row_bytes = t.element_size() * int(np.prod(t.shape[1:])) if t.dim() > 1 else t.element_size()
+    if rank != dst:
+        if counts[rank] > 0:
+            dist.send(t, dst, group=group)
+        return None, counts[rank] * row_bytes, 0
+    parts, recv = [], 0
+    for r in range(world):
+        if r == rank:
+            parts.append(t)
+            continue
+        buf = torch.empty((counts[r],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        if counts[r] > 0:
+            dist.recv(buf, src=r, group=group)
+            recv += counts[r] * row_bytes
+        parts.append(buf)
+    return parts, 0, recv
+
+
+def gather_records_to(ir: np.ndarray, fr: np.ndarray, ct: np.ndarray, dst: int = 0, device=None, group=None):
+    """The packed records of all ranks on rank `dst` only (rank order preserved) — the writer's gather: only one rank writes the
+    slide's files (cell_detection.py:423-475).  Returns ((ir, fr, ct) on `dst`, None elsewhere; bytes sent; bytes received)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return (ir, fr, ct), 0, 0
+    dev = device or torch.device("cpu")
+    sent = recv = 0
+    out = []
+    for a in (ir, fr, ct):
+        parts, s_, r_ = _gather_var_to(torch.from_numpy(np.ascontiguousarray(a)).to(dev), dst, group)
+        sent += s_; recv += r_
+        out.append(torch.cat(parts).cpu().numpy() if parts is not None else None)
+    return (tuple(out) if out[0] is not None else None), sent, recv
+
+
+def gather_rows_to(t: torch.Tensor, dst: int = 0, group=None):
+    """gatherv of a [n, ...] tensor along dim 0 to rank `dst` (rank order).  Returns (tensor on `dst` / None, bytes sent, received)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t, 0, 0
+    parts, s_, r_ = _gather_var_to(t.contiguous(), dst, group)
+    return (torch.cat(parts) if parts is not None else None), s_, r_
+
+
 def all_gather_int(v: int, device=None, group=None) -> List[int]:
     """One integer from every rank (rank order); [v] without an initialised process group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

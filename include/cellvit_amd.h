@@ -209,7 +209,7 @@ typedef struct cv_instance {
 } cv_instance;
 
 typedef struct cv_pp cv_pp;
-/* max_inst record slots and max_pts contour points per tile; nr_types <= 8. */
+/* max_inst record slots and max_pts contour points per tile; nr_types <= 256 (u8 type planes; more than 8 classes vote in windows of 8). */
 int cv_pp_create(int max_batch, int H, int W, int max_inst, int max_pts, cv_pp** out);
 int cv_pp_destroy(cv_pp* pp);
 /* Device inputs: bin_argmax / type_argmax u8 [B,H,W] (cellvit.py:369-374), hv f32 [B,2,H,W].

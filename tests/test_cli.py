@@ -292,6 +292,56 @@ def test_world2_with_a_rank_that_received_no_tile():
         assert np.array_equal(tok, ref_all.tokens.numpy())
 
 
+def _writer_gather_worker(rank, world, port, q, outdir, grid=3, block=2):
+    import torch.distributed as dist
+    from cellvit_amd import sharding as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tiles = _synthetic_slide_tiles(grid=grid)
+    local = _slide_cells_of(tiles, S.shard_tiles(grid * grid, rank, world, block=block), grid=grid)
+    tm: dict = {}
+    allc, dicts = CD.finalize_slide(local, 1024, 1, 64, timings=tm, want_dicts=False, gather_to=0)
+    if rank == 0:
+        CD.write_outputs(outdir, {"magnification": 40}, ["0_0"], {"Background": 0}, allc, False, 1024, 1, 64)
+    q.put((rank, None if allc is None else len(allc), tm))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_writer_gather_files_are_byte_identical_to_world1(tmp_path):
+    """The CLI's collection step (`gather_to=0`): kept cells + token rows go to the writer rank ONLY, point to point with exact
+    sizes.  Rank 1 ends with nothing, sends its own cells once and receives nothing; rank 0's files are byte-identical to the
+    single-process run's."""
+    import socket
+    import torch.multiprocessing as mp
+    tiles = _synthetic_slide_tiles()
+    ref_all, _ = CD.finalize_slide(_slide_cells_of(tiles, list(range(9))), 1024, 1, 64, want_dicts=False)
+    d1, d2 = tmp_path / "w1", tmp_path / "w2"
+    d1.mkdir(); d2.mkdir()
+    CD.write_outputs(d1, {"magnification": 40}, ["0_0"], {"Background": 0}, ref_all, False, 1024, 1, 64)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_writer_gather_worker, args=(r, 2, port, q, d2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, t0), (_, n1, t1) = res
+    assert n0 == len(ref_all) and n1 is None
+    assert t0["n_cells_total"] == t1["n_cells_total"] == len(ref_all)
+    assert t1["writer_gather_bytes_received"] == 0 and t1["writer_gather_bytes_sent"] > 0
+    assert t0["writer_gather_bytes_sent"] == 0 and t0["writer_gather_bytes_received"] == t1["writer_gather_bytes_sent"]
+    for name in ("cells.json", "cell_detection.json", "cells.pt"):
+        a, b = (d1 / name).read_bytes(), (d2 / name).read_bytes()
+        assert a == b and len(a) > 100, name
+
+
 def test_cells_pt_wire_format(tmp_path):
     """cells.pt is the reference's CellGraphDataWSI dataclass, pickled under the reference's module path
     (cell_detection.py:469-475, cell_graph_datamodel.py:18-26): x, positions, metadata, contours."""

@@ -182,6 +182,59 @@ def test_calculate_instances_equals_the_oracle_records():
     assert torch.equal(inst_t, torch.from_numpy(np.stack(insts)).cuda())          # the caller's map is not modified
 
 
+@pytest.mark.gpu
+def test_calculate_instances_with_more_than_eight_classes():
+    """post_proc_cellvit.py:300-318 votes with np.unique (no class limit): 12 and 19 classes on the device (windows of 8 types)
+    == the oracle, incl. equal counts (the lower type wins) and background replaced by a runner-up above type 7; the
+    prediction path (`cv_pp_run`) takes the same vote."""
+    from oracle import postproc_ref as O
+    from cellvit_amd.postproc import calculate_instances, postprocess_device, records_to_dicts, _params
+    rng = np.random.default_rng(5)
+    for nr in (12, 19):
+        insts, tmaps = [], []
+        for s in range(2):
+            inst, tmap, _, _ = _case(60 + s, size=256)
+            tm = rng.integers(0, nr, tmap.shape).astype(np.uint8)            # noisy votes over all classes
+            ids = np.unique(inst)[1:]
+            for k, i in enumerate(ids):                                      # most instances: one dominant class, many above 7
+                m = inst == i
+                sel = m & (rng.random(inst.shape) < 0.6)
+                tm[sel] = (k * 5 + 3) % nr
+            if len(ids) > 3:
+                ys, xs = np.nonzero(inst == ids[0])                          # exact tie between types 9 and 11: the lower wins
+                tm[ys, xs] = np.where(np.arange(len(ys)) % 2 == 0, 9, 11)[:len(ys)] if len(ys) % 2 == 0 else tm[ys, xs]
+                ys, xs = np.nonzero(inst == ids[1])                          # background majority, runner-up type 10
+                tm[ys, xs] = 0
+                tm[ys[: max(1, len(ys) // 3)], xs[: max(1, len(ys) // 3)]] = 10
+            insts.append(inst); tmaps.append(tm)
+        inst_t = torch.from_numpy(np.stack(insts)).cuda()
+        onehot = torch.nn.functional.one_hot(torch.from_numpy(np.stack(tmaps)).long(), nr).permute(0, 3, 1, 2).float().cuda()
+        got = calculate_instances(onehot, inst_t)
+        seen = set()
+        for b in range(2):
+            want = O.instances(insts[b], tmaps[b], nr)
+            assert list(got[b].keys()) == list(want.keys()) and len(want) > 10
+            for k in want:
+                assert got[b][k]["type"] == want[k]["type"] and got[b][k]["type_prob"] == want[k]["type_prob"], (nr, b, k)
+                assert np.array_equal(got[b][k]["contour"], want[k]["contour"])
+                seen.add(want[k]["type"])
+        assert max(seen) > 8 and len(seen) > 6
+    # prediction path with 12 classes: same records as the oracle's full chain
+    nr = 12
+    inst, tmap, bm, hvm = _case(70, size=256)
+    tm = ((tmap.astype(np.int64) * 5) % nr).astype(np.uint8)
+    obj, ks = _params(40)
+    dev = torch.device("cuda", 0)
+    i_d, recs, n_recs, contours, n_pts = postprocess_device(torch.from_numpy((inst > 0).astype(np.uint8))[None].to(dev), torch.from_numpy(tm)[None].to(dev),
+                                                            torch.from_numpy(np.ascontiguousarray(hvm))[None].to(dev), nr, obj, ks)
+    got = records_to_dicts(recs, n_recs, contours, n_pts)[0]
+    pm = np.stack([tm.astype(np.float32), (inst > 0).astype(np.float32), hvm[0], hvm[1]], -1)
+    i_o, want = O.postprocess_tile(pm, nr, 40)
+    assert np.array_equal(i_d[0].cpu().numpy(), i_o) and list(got.keys()) == list(want.keys()) and len(want) > 5
+    for k in want:
+        assert got[k]["type"] == want[k]["type"] and got[k]["type_prob"] == want[k]["type_prob"]
+
+
 class _MapsModel:
     """Stand-in network: returns logits whose argmax / HV maps are the synthetic ground truth, then the REAL
     calculate_instance_map / generate_instance_nuclei_map of the shim (C-ABI post-processing)."""
