@@ -25,6 +25,8 @@ struct AttnParams {
     int win, gw, gh, nwx, nwy;
     void* win_prep;         // >= 32 KiB device scratch for attention_win.hip (rel-pos operands of the layer), or null
     int dbg;                // experiment switches (attention_win.hip, CVA_ATTNW_DBG)
+    int v_rm;               // `Vt` holds V ROW-major [S*heads, L, hd] (same layout as K): the kernels read the PV operand through the
+                            // transposing LDS read ds_read_b64_tr_b16 (fp16, hd 80: attn2_kernel and attnwp_kernel; see attn_takes_vrm)
 };
 
 struct RelPosParams {
@@ -39,15 +41,17 @@ struct PadKVParams {        // window mode: keys/values of zero-padded tokens ar
     void* K; void* Vt;      // T
     const float* qkv_bias;  // [3*D]
     int B, heads, hd, D, L, Lp, win, gw, gh, nwx, nwy;
+    int v_rm;               // Vt is V row-major [S*heads, L, hd]
 };
 
+// Row-major V (v_rm): true when the kernels the dispatcher of cellvit_abi.hip would choose for this layer geometry both exist in the
+// v_rm form — fp16, hd 80 (LDS row pitch 160 B = 40 dwords: the 8 keys a half-wave of ds_read_b64_tr_b16 touches fall on 8 distinct
+// 8-bank groups), windows on the persistent single-pass kernel (tables present, 192 < nk <= 208, >= 64 (window, head) items), global
+// blocks on attn2_kernel.  The decision is taken once per geometry (cv_set_geometry) for ALL blocks of the encoder.
+bool attn_takes_vrm(const AttnParams& p, size_t elem_size);
 template <typename T> int launch_attention(const AttnParams& p, hipStream_t stream);
 // v2 (attention2.hip): fused rel-pos; returns -1 when the geometry is not covered (caller uses v1 + launch_relpos)
 template <typename T> int launch_attention2(const AttnParams& p, hipStream_t stream);
-// attention3.hip: fp16 global attention (no windows, >= 256 keys, hd 64 / 80; rel-pos only in the key-tile-aligned form KW == 64):
-// one 8-wave workgroup per CU, MFMA and softmax phases of the two wave groups in counter-phase, LDS-DMA staging.  -1 when not covered.
-// Measured equal to attention2 (the two pipes of a SIMD do not overlap across waves): ablation builds only, production returns -1.
-int launch_attention3(const AttnParams& p, hipStream_t stream);
 // attention_win.hip: single-pass kernel for <= 208 keys (SAM windows), fp16 only; -1 when not covered
 int launch_attention_win(const AttnParams& p, hipStream_t stream);
 template <typename T> int launch_relpos(const RelPosParams& p, hipStream_t stream);

@@ -261,12 +261,15 @@ __global__ void pad_kv_kernel(const PadKVParams p) {
         const int h = c / p.hd, d = c - h * p.hd;
         reinterpret_cast<T*>(p.K)[(((long)s * p.heads + h) * p.L + pos) * p.hd + d] =
             Traits<T>::from_float(p.qkv_bias[p.D + c]);
+        if (p.v_rm)      // V row-major: the same element of the V image
+            reinterpret_cast<T*>(p.Vt)[(((long)s * p.heads + h) * p.L + pos) * p.hd + d] = Traits<T>::from_float(p.qkv_bias[2 * p.D + c]);
     }
     // V^T [s, h, d, pos]: position fastest (the padded positions of one row are a few contiguous runs)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i / npad);
         const int pos = pad_pos((int)(i - (long)c * npad));
         const int h = c / p.hd, d = c - h * p.hd;
+        if (p.v_rm) continue;
         reinterpret_cast<T*>(p.Vt)[(((long)s * p.heads + h) * p.hd + d) * p.Lp + pos] =
             Traits<T>::from_float(p.qkv_bias[2 * p.D + c]);
     }

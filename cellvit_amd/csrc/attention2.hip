@@ -50,8 +50,23 @@ __device__ __forceinline__ typename Traits<T>::Frag frag_from_2x4(const T* p0, c
     return f;
 }
 
-template <typename T, int HD, int BIAS, int NBK>
+// V ROW-major (VRM, fp16): the V tile is staged as it lies in memory, [key][HD] with the unpadded pitch of HD halves, and the PV operand
+// (A = V^T rows d = n*16 + li, keys 4g .. 4g+3 of two key blocks) comes out of the transposing LDS read: lane (g, i) of a 16-lane group
+// passes the address of key 4g + i/4, elements d0 + 4 (i%4) .. +3, and receives V[4g + r][d0 + i], r = 0..3 (measured:
+// tools/probes/probe_ds_read_tr.hip, profiles/r04_probe_ds_read_tr.txt).  With HD = 80 the pitch is 40 dwords: the 8 keys a half-wave
+// touches start on 8 distinct multiples of 8 banks.
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half8_t frag_tr_2x4(const half_t* p0, const half_t* p1) {
+    typedef __attribute__((address_space(3))) fp16x4_t* lp;
+    const h4_t a = __builtin_bit_cast(h4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(__attribute__((address_space(3))) void*)const_cast<half_t*>(p0)));
+    const h4_t b = __builtin_bit_cast(h4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(__attribute__((address_space(3))) void*)const_cast<half_t*>(p1)));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <typename T, int HD, int BIAS, int NBK, int VRM = 0>
 __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
+    static_assert(!VRM || (sizeof(T) == 2 && HD == 80), "row-major V: fp16, hd 80 (conflict-free pitch of the transposing read)");
     using TR = Traits<T>;
     using Frag = typename TR::Frag;
     constexpr int PE = TR::PIECE;
@@ -83,7 +98,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
 
     const T* __restrict__ Qg = reinterpret_cast<const T*>(p.Q) + (long)sh * p.L * HD;
     const T* __restrict__ Kg = reinterpret_cast<const T*>(p.K) + (long)sh * p.L * HD;
-    const T* __restrict__ Vg = reinterpret_cast<const T*>(p.Vt) + (long)sh * HD * p.Lp;
+    const T* __restrict__ Vg = reinterpret_cast<const T*>(p.Vt) + (VRM ? (long)sh * p.L * HD : (long)sh * HD * p.Lp);
 
     if (HDP > HD) {
         for (int i = tid; i < KT * (HDP - HD); i += NT) {
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     // K / V^T tiles are fetched one tile ahead into registers (issue early, write to LDS after the barrier):
     // the global-memory latency of tile kt+1 hides behind the MFMAs of tile kt.
     constexpr int KPPR = HD / PE, VPPR = KT / PE;
-    constexpr int KN = (KT * KPPR + NT - 1) / NT, VN = (HD * VPPR + NT - 1) / NT;
+    constexpr int KN = (KT * KPPR + NT - 1) / NT, VN = VRM ? KN : (HD * VPPR + NT - 1) / NT;
     Piece kreg[KN], vreg[VN];
     // LAST (compile time): only the last key tile can hold keys >= nk; every other tile skips the bounds tests and the
     // per-element tail zeroing (the optimiser turned those into ~140 selects per tile, executed on every tile)
@@ -119,6 +134,16 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             const int r = i / KPPR, c = i - r * KPPR;
             const int key = kt * KT + r;
             kreg[u] = (i < KT * KPPR && (!LAST || key < p.nk)) ? load_piece(Kg + (long)key * HD + c * PE) : zero_piece();
+        }
+        if constexpr (VRM) {      // the V tile is one contiguous run of KT rows of HD halves, like the K tile
+#pragma unroll
+            for (int u = 0; u < VN; ++u) {
+                const int i = tid + u * NT;
+                const int r = i / KPPR, c = i - r * KPPR;
+                const int key = kt * KT + r;
+                vreg[u] = (i < KT * KPPR && (!LAST || key < p.nk)) ? load_piece(Vg + (long)key * HD + c * PE) : zero_piece();
+            }
+            return;
         }
 #pragma unroll
         for (int u = 0; u < VN; ++u) {
@@ -268,7 +293,9 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
 #pragma unroll
         for (int u = 0; u < VN; ++u) {
             const int i = tid + u * NT;
-            if (i < HD * VPPR) {
+            if constexpr (VRM) {
+                if (i < KT * KPPR) store_piece(Vts + i * PE, vreg[u]);      // [key][HD], pitch HD: the tile image is linear
+            } else if (i < HD * VPPR) {
                 const int d = i / VPPR, c = i - d * VPPR;
                 if constexpr (sizeof(T) == 2) {
                     unsigned long long* dst = reinterpret_cast<unsigned long long*>(Vts + d * PV + c * PE);
@@ -393,8 +420,14 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             if (2 * m >= nkb) continue;                           // all P of these 32 keys are exactly 0
 #pragma unroll
             for (int n = 0; n < ND; ++n) {
-                const T* vrow = Vts + (n * 16 + li) * PV + g * 4;
-                const Frag vf = frag_from_2x4<T>(vrow + (2 * m) * 16, vrow + (2 * m + 1) * 16);
+                Frag vf;
+                if constexpr (VRM) {
+                    const half_t* vkey = reinterpret_cast<const half_t*>(Vts) + ((2 * m) * 16 + g * 4 + (li >> 2)) * HD + n * 16 + (li & 3) * 4;
+                    vf.v = frag_tr_2x4(vkey, vkey + 16 * HD);
+                } else {
+                    const T* vrow = Vts + (n * 16 + li) * PV + g * 4;
+                    vf = frag_from_2x4<T>(vrow + (2 * m) * 16, vrow + (2 * m + 1) * 16);
+                }
                 TR::mma(vf, pf[0][m], o[0][n]);
                 TR::mma(vf, pf[1][m], o[1][n]);
             }
@@ -436,7 +469,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     }
 }
 
-template <typename T, int HD, int BIAS, int NBK>
+template <typename T, int HD, int BIAS, int NBK, int VRM = 0>
 int launch_attn2_impl(const AttnParams& p, hipStream_t stream) {
     constexpr int HDP = (HD + 31) / 32 * 32;
     size_t lds = (size_t)(KT * lds_pitch<T>(HDP) + HD * lds_pitch<T>(KT)) * sizeof(T);   // (V^T pitch <= lds_pitch)
@@ -444,18 +477,27 @@ int launch_attn2_impl(const AttnParams& p, hipStream_t stream) {
     if (BIAS == 2) lds += (size_t)QT * (128 + 8) * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<T, HD, BIAS, NBK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<T, HD, BIAS, NBK, VRM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((p.L + QT - 1) / QT, p.S * p.heads);
-    hipLaunchKernelGGL((attn2_kernel<T, HD, BIAS, NBK>), grid, dim3(NT), lds, stream, p);
+    hipLaunchKernelGGL((attn2_kernel<T, HD, BIAS, NBK, VRM>), grid, dim3(NT), lds, stream, p);
     return (int)hipGetLastError();
 }
 
 template <typename T, int HD>
 int launch_attn2_hd(const AttnParams& p, hipStream_t stream) {
+    if (p.v_rm) {      // row-major V: fp16, hd 80 only (attn_takes_vrm)
+        if constexpr (sizeof(T) == 2 && HD == 80) {
+            if (!p.tab_h) return launch_attn2_impl<T, HD, 0, 1, 1>(p, stream);
+            if (p.KW == KT && p.KH <= 64 && p.nk == p.KH * p.KW) return launch_attn2_impl<T, HD, 2, 1, 1>(p, stream);
+            if (p.KH + p.KW <= 32) return launch_attn2_impl<T, HD, 1, 1, 1>(p, stream);
+            if (p.KH + p.KW <= 64) return launch_attn2_impl<T, HD, 1, 2, 1>(p, stream);
+        }
+        return (int)hipErrorInvalidValue;
+    }
     if (!p.tab_h) return launch_attn2_impl<T, HD, 0, 1>(p, stream);
     if (p.KW == KT && p.KH <= 64 && p.nk == p.KH * p.KW) return launch_attn2_impl<T, HD, 2, 1>(p, stream);
     if (p.KH + p.KW <= 32) return launch_attn2_impl<T, HD, 1, 1>(p, stream);

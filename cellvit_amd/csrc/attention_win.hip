@@ -396,8 +396,22 @@ struct AttnwpGeom {
     }
 };
 
-template <int HD, int BIAS>
+// VRM = 1 (AttnParams::v_rm, hd 80): V arrives ROW-major [L][HD] like K.  Its LDS image is then the item's V rows as they lie in
+// memory (208 rows x 160 B, DMA'd like K — no register staging, no transposing LDS stores), and the PV operand comes out of
+// ds_read_b64_tr_b16 (see attention2.hip).  One V image: the DMA of item i's V is issued at the top of item i (the image was released
+// by the barrier that ends item i-1) and has the relcat + S^T phase to land; a barrier after S^T publishes it (two barriers per item,
+// as before).
+typedef __fp16 w_fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ half8_t w_frag_tr_2x4(const half_t* p0, const half_t* p1) {
+    typedef __attribute__((address_space(3))) w_fp16x4_t* lp;
+    const half4_t a = __builtin_bit_cast(half4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(__attribute__((address_space(3))) void*)const_cast<half_t*>(p0)));
+    const half4_t b = __builtin_bit_cast(half4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(__attribute__((address_space(3))) void*)const_cast<half_t*>(p1)));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int HD, int BIAS, int VRM = 0>
 __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
+    static_assert(!VRM || HD == 80, "row-major V: hd 80");
     using GM = AttnwpGeom<HD>;
     constexpr int PE = 8;
     constexpr int HDP = GM::HDP, NKS = HDP / 32, ND = HD / 16;
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
     half_t* __restrict__ out = reinterpret_cast<half_t*>(p.out);
 
     // ---- once per workgroup: zero the V^T image (pad columns and keys past nk stay zero for good), stage E and the tables
-    for (int i = tid; i < HD * PVF / 4; i += PNT) reinterpret_cast<unsigned long long*>(Vts)[i] = 0ull;
+    if (!VRM) for (int i = tid; i < HD * PVF / 4; i += PNT) reinterpret_cast<unsigned long long*>(Vts)[i] = 0ull;
     for (int i = tid; i < (PNT / 64) * WQW * PE1 / PE; i += PNT) store_piece(Rc + i * PE, zero_piece());
     if (BIAS) {
         const half_t* __restrict__ prepE = reinterpret_cast<const half_t*>(p.win_prep);
@@ -460,14 +474,41 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         }
     };
 
+    // VRM: the V image = the item's WKEYS rows of HD halves, linear; piece j <- source piece min(j, nk * KPPR - 1) (clamped: rows past
+    // nk hold finite data that only meets P = 0)
+    constexpr int NDMAV = (WKEYS * GM::KPPR + 63) / 64;  // 33 for hd 80
+    constexpr int DPWV = (NDMAV + 7) / 8;
+    unsigned vvoff[VRM ? DPWV : 1];
+    if constexpr (VRM) {
+#pragma unroll
+        for (int t = 0; t < DPWV; ++t) {
+            int j = (wave + 8 * t) * 64 + lane;
+            j = j < p.nk * GM::KPPR ? j : p.nk * GM::KPPR - 1;
+            vvoff[t] = (unsigned)j * 16u;
+        }
+    }
+    auto dma_v = [&](int sh) {
+        if constexpr (VRM) {
+            const unsigned char* base = uniform_ptr_w(Vb + (long)sh * p.L * HD);
+#pragma unroll
+            for (int t = 0; t < DPWV; ++t) {
+                const int u = wave + 8 * t;
+                if (u < NDMAV) {                         // wave-uniform
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(ldsK + (unsigned)(2 * GM::KIMG) * 2u + (unsigned)u * 1024u);
+                    AW_DMA(vvoff[t], base, dst);
+                }
+            }
+        }
+    };
     constexpr int VPPR = WKEYS / PE;                    // 26 pieces per V^T row
-    constexpr int VN = (HD * VPPR + PNT - 1) / PNT;
+    constexpr int VN = VRM ? 1 : (HD * VPPR + PNT - 1) / PNT;
     Piece vreg[VN];
     half8_t qf[2][NKS];
     const int q0 = wave * WQW;
     const bool wave_active = q0 < p.L;
 
     auto load_v = [&](int sh) {
+        if constexpr (VRM) return;
         const half_t* __restrict__ Vg = Vb + (long)sh * HD * p.Lp;
 #pragma unroll
         for (int u = 0; u < VN; ++u) {
@@ -477,6 +518,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         }
     };
     auto store_v = [&]() {
+        if constexpr (VRM) return;
 #pragma unroll
         for (int u = 0; u < VN; ++u) {
             const int i = tid + u * PNT;
@@ -517,10 +559,16 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
 
     for (; it < nitems; it += gridDim.x, buf ^= 1) {
         const half_t* Ks = Ks0 + buf * GM::KIMG;
-        store_v();
-        __syncthreads();                                // V^T of this item visible (its K image was fenced by the previous barrier)
         const int nxt = it + gridDim.x;
-        if (nxt < nitems) { dma_k(nxt, buf ^ 1); load_v(nxt); }   // in flight during this item's compute
+        if constexpr (VRM) {
+            // (every wave is past the barrier that ended the previous item: the V image and K image buf ^ 1 are free)
+            dma_v(it);                                  // lands during the relcat + S^T phase; published by the barrier behind S^T
+            if (nxt < nitems) dma_k(nxt, buf ^ 1);
+        } else {
+            store_v();
+            __syncthreads();                            // V^T of this item visible (its K image was fenced by the previous barrier)
+            if (nxt < nitems) { dma_k(nxt, buf ^ 1); load_v(nxt); }   // in flight during this item's compute
+        }
 
         // Loop-invariant per-lane predicates and addresses (key < nk, the rel-pos scatter conditions, ...) would be hoisted
         // out of the item loop and cost > 100 SGPRs / VGPRs of live state: re-derive them per item from opaque copies.
@@ -606,6 +654,10 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                     __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs between their wait and the ring refill
                 });
             }
+            if constexpr (VRM) {                        // this wave's share of V(it) (and of K(next)) has landed; then everybody's
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             if (nxt < nitems) load_q(nxt);              // Q of the next item: in flight during the softmax and PV
 
             // ---- one-pass softmax in the log2 domain, P^T fragments, O^T = V^T . P^T
@@ -659,10 +711,30 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
             {
                 // V^T fragments: key blocks 2m and 2m+1 of row n*16 + li (two 8-byte halves, 32 B apart); block 13 does not
                 // exist (its P is 0): block 12 is read again instead.  Same 4-deep ring as above.
+                constexpr int TP = 7 * ND;
+                if constexpr (VRM) {
+                    // row-major image: lane (g, i) addresses key 4g + i/4 of the block, elements n*16 + 4 (i%4) ..; the transposing read
+                    // hands lane (g, li) V[4g + r][n*16 + li].  Compiler-visible loads (counted waits by the compiler), issued four steps
+                    // ahead through the same ring; sched_barrier keeps them there.
+                    const half_t* vbase = Vts + (g * 4 + (li >> 2)) * HD + (li & 3) * 4;
+                    auto rdv = [&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        constexpr int m = t / ND, n = t - m * ND;
+                        ring[t & 3] = w_frag_tr_2x4(vbase + (2 * m) * 16 * HD + n * 16, vbase + (m == 6 ? 2 * m : 2 * m + 1) * 16 * HD + n * 16);
+                    };
+                    static_for<4>(rdv);
+                    static_for<TP>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        constexpr int m = t / ND, n = t - m * ND;
+                        o[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[t & 3], pf[0][m], o[0][n], 0, 0, 0);
+                        o[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[t & 3], pf[1][m], o[1][n], 0, 0, 0);
+                        if constexpr (t + 4 < TP) rdv(std::integral_constant<int, t + 4>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                } else {
                 unsigned vb[ND];
 #pragma unroll
                 for (int n = 0; n < ND; ++n) vb[n] = ldsK + (unsigned)(2 * GM::KIMG) * 2u + (unsigned)((n * 16 + li) * PVF + g * 4) * 2u;
-                constexpr int TP = 7 * ND;
                 auto rd = [&](auto tc) {
                     constexpr int t = decltype(tc)::value;
                     constexpr int m = t / ND, n = t - m * ND;
@@ -682,6 +754,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                     if constexpr (t + 4 < TP) rd(std::integral_constant<int, t + 4>{});
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                }
             }
 
             // ---- normalise and store; lane holds O[query li of qb][d = n*16 + g*4 + r].  This wave's prefetches (K DMA,
@@ -714,6 +787,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (VRM) __builtin_amdgcn_s_barrier();   // the barrier behind the active waves' S^T phase
         }
         __syncthreads();                                // every wave is done with this item's K / V^T; the next K image has landed
     }
@@ -771,9 +845,24 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
         }
         const size_t ldsp = AttnwpGeom<HD>::lds_bytes();
         const int items = p.S * p.heads;
+        if (p.v_rm) {
+            if constexpr (HD == 80 && BIAS) {
+                static bool attr_v = false;
+                if (!attr_v) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attnwp_kernel<HD, BIAS, 1>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) return (int)e;
+                    attr_v = true;
+                }
+                hipLaunchKernelGGL((attnwp_kernel<HD, BIAS, 1>), dim3(items < n_cu ? items : n_cu), dim3(PNT), ldsp, stream, p);
+                return (int)hipGetLastError();
+            }
+            return (int)hipErrorInvalidValue;
+        }
         hipLaunchKernelGGL((attnwp_kernel<HD, BIAS>), dim3(items < n_cu ? items : n_cu), dim3(PNT), ldsp, stream, p);
         return (int)hipGetLastError();
     }
+    if (p.v_rm) return (int)hipErrorInvalidValue;        // the other window kernels read V^T
     dim3 grid(p.S * p.heads);                            // one workgroup per (sequence, head); <= 2 query passes inside
     hipLaunchKernelGGL((attnw_kernel<HD, BIAS>), grid, dim3(WNT), lds, stream, p);
     return (int)hipGetLastError();
@@ -785,12 +874,26 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
 int launch_attention_win(const AttnParams& p_in, hipStream_t stream) {
     AttnParams p = p_in;
     { static const int dbg = cva_env_int("CVA_ATTNW_DBG", 0); p.dbg = dbg; }   // ablation builds only
-    if (p.nk > WKEYS || p.nk != p.L || p.Lp < WKEYS) return -1;
+    if (p.nk > WKEYS || p.nk != p.L || (p.Lp < WKEYS && !p.v_rm)) return -1;
     const bool bias = p.tab_h && p.tab_w;
-    if (bias && (p.KH > 16 || p.KW > 16 || p.nk != p.KH * p.KW || !p.win_prep)) return -1;
+    if (bias && (p.KH > 16 || p.KW > 16 || p.nk != p.KH * p.KW || !p.win_prep)) return -1;      // (attn_takes_vrm mirrors these tests)
     if (p.hd == 80) return bias ? launch_attnw_impl<80, 1>(p, stream) : launch_attnw_impl<80, 0>(p, stream);
     if (p.hd == 64) return bias ? launch_attnw_impl<64, 1>(p, stream) : launch_attnw_impl<64, 0>(p, stream);
     return -1;
+}
+
+// (attention.h) the geometry test the dispatcher of cellvit_abi.hip makes, for the row-major V forms of the two production kernels
+bool attn_takes_vrm(const AttnParams& p, size_t elem_size) {
+    static const int persistent = cva_env_int("CVA_ATTNW_P", 1), variant = cva_env_int("CVA_ATTN", 3), off = cva_env_int("CVA_NO_VRM", 0);
+    if (elem_size != 2 || p.hd != 80 || !persistent || variant != 3 || off) return false;
+    const bool bias = p.tab_h && p.tab_w;
+    // would launch_attention_win take this layer (short key sequences, window OR global)?  Then only its persistent kernel reads row-major V
+    const bool short_seq = p.nk <= WKEYS && p.nk == p.L && p.Lp >= WKEYS &&
+                           !(bias && (p.KH > 16 || p.KW > 16 || p.nk != p.KH * p.KW || !p.win_prep));
+    if (short_seq) return bias && p.nk > (WNKB - 1) * 16 && p.S * p.heads >= 64;
+    // everything else runs attn2_kernel (or falls through to v1 when its bias forms do not fit)
+    if (!bias) return true;
+    return (p.KW == 64 && p.KH <= 64 && p.nk == p.KH * p.KW) || p.KH + p.KW <= 64;
 }
 
 }  // namespace cva

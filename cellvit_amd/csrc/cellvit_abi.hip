@@ -114,6 +114,7 @@ struct Geometry {
     bool set = false;
     int B = 0, H = 0, W = 0, gh = 0, gw = 0, P = 0, ntok = 0, has_cls = 0;
     int nwy = 0, nwx = 0, Lw = 0, Lpw = 0, Lg = 0, Lpg = 0;
+    int v_rm = 0;      // V of every attention layer is kept ROW-major [S*heads, L, hd] (attention.h attn_takes_vrm)
 };
 
 }  // namespace
@@ -655,7 +656,7 @@ template <typename T>
 int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, const float* tab_w, bool window,
                         void* Q, void* K, void* Vt, float* relh, float* relw, void* attn_out, int B, int gh, int gw,
                         int has_cls, int heads, int D, int ws, hipStream_t st, bool prepadded = false,
-                        const void* xn_sca = nullptr, const void* xn_scw = nullptr, int Mp = 0) {
+                        const void* xn_sca = nullptr, const void* xn_scw = nullptr, int Mp = 0, int v_rm = -1) {
     const int hd = D / heads, P = gh * gw, ntok = P + has_cls;
     const int nwy = window ? (gh + ws - 1) / ws : 0, nwx = window ? (gw + ws - 1) / ws : 0;
     const int L = window ? ws * ws : ntok, Lp = round_up(L, 64);
@@ -666,8 +667,20 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
         if (qkv.Np > g.N) { g.n_valid = g.N; g.N = qkv.Np; }
         if (Mp > g.M) { g.m_valid = g.M; g.M = Mp; }
     }
+    const int KH = window ? ws : gh, KW = window ? ws : gw;
+    AttnParams a{};
+    a.Q = Q; a.K = K; a.Vt = Vt; a.out = attn_out;
+    a.S = S; a.heads = heads; a.L = L; a.Lp = Lp; a.hd = hd; a.D = D; a.nk = L; a.KH = KH; a.KW = KW;
+    a.scale = 1.0f / std::sqrt((float)hd);
+    a.ntok = ntok; a.win = window ? ws : 0; a.gw = gw; a.gh = gh; a.nwx = nwx; a.nwy = nwy;
+    a.tab_h = tab_h; a.tab_w = tab_w;
+    a.win_prep = ((size_t)S * heads * L * KH * 4 >= 32768) ? (void*)relh : nullptr;   // the v1 bias scratch doubles as the window kernel's prep area
+    // V layout of this layer: the engine decides once per geometry (all blocks alike: the per-block V buffers of padded window grids
+    // are pre-filled in that layout); single-layer callers (cv_op_attention) decide here
+    if (v_rm < 0) v_rm = (!xn_sca && attn_takes_vrm(a, sizeof(T))) ? 1 : 0;
+    a.v_rm = v_rm;
     g.bias = qkv.bias; g.act = ACT_NONE; g.out_mode = OUT_QKV;
-    g.q_out = Q; g.k_out = K; g.vt_out = Vt;
+    g.q_out = Q; g.k_out = K; g.vt_out = Vt; g.v_rm = v_rm;
     g.D = D; g.hd = hd; g.heads = heads; g.ntok = ntok; g.L = L; g.Lp = Lp;
     g.win = window ? ws : 0; g.gw = gw; g.gh = gh; g.nwx = nwx; g.nwy = nwy;
     if (xn_sca) {      // fp8 engine: xn is the MX-fp8 image written by the LayerNorm, qkv.W8 / S8 the packed weight
@@ -679,27 +692,19 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
     if (!prepadded && window && (nwy * ws != gh || nwx * ws != gw)) {
         PadKVParams pk{};
         pk.K = K; pk.Vt = Vt; pk.qkv_bias = qkv.bias; pk.B = B; pk.heads = heads; pk.hd = hd; pk.D = D; pk.L = L;
-        pk.Lp = Lp; pk.win = ws; pk.gw = gw; pk.gh = gh; pk.nwx = nwx; pk.nwy = nwy;
+        pk.Lp = Lp; pk.win = ws; pk.gw = gw; pk.gh = gh; pk.nwx = nwx; pk.nwy = nwy; pk.v_rm = v_rm;
         CVA_LAUNCH(launch_pad_kv<T>(pk, st));
     }
-    const int KH = window ? ws : gh, KW = window ? ws : gw;
-    AttnParams a{};
-    a.Q = Q; a.K = K; a.Vt = Vt; a.out = attn_out;
-    a.S = S; a.heads = heads; a.L = L; a.Lp = Lp; a.hd = hd; a.D = D; a.nk = L; a.KH = KH; a.KW = KW;
-    a.scale = 1.0f / std::sqrt((float)hd);
-    a.ntok = ntok; a.win = window ? ws : 0; a.gw = gw; a.gh = gh; a.nwx = nwx; a.nwy = nwy;
-    static const int attn_variant = cva_env_int("CVA_ATTN", 3);   // 3: window kernel + v2, 5: window kernel + v3 (attention3.hip, measured not faster) + v2, 2: v2 only, 1: v1
+    static const int attn_variant = cva_env_int("CVA_ATTN", 3);   // 3: window kernel + v2, 2: v2 only, 1: v1
     if (attn_variant != 1) {
-        a.tab_h = tab_h; a.tab_w = tab_w;
         ProfScope ps(KC_ATTN, 4.0 * (double)B * P * (window ? L : ntok) * hd * heads + (window ? 0.0 : 4.0 * B * has_cls * (double)ntok * hd * heads), st);
         int rc2 = -1;
-        a.win_prep = ((size_t)S * heads * L * KH * 4 >= 32768) ? (void*)relh : nullptr;   // the v1 bias scratch doubles as the window kernel's prep area
         if (sizeof(T) == 2 && attn_variant != 2) rc2 = launch_attention_win(a, st);     // short key sequences (windows)
-        if (rc2 == -1 && sizeof(T) == 2 && attn_variant == 5) rc2 = launch_attention3(a, st);   // experiment (ablation builds): 8-wave counter-phase kernel
         if (rc2 == -1) rc2 = launch_attention2<T>(a, st);
         if (rc2 == 0) return CV_OK;
         if (rc2 != -1) { cva_set_error("attention2 launch failed (%d)", rc2); return CV_ERR_HIP; }
     }
+    if (v_rm) { cva_set_error("attention: row-major V without a kernel that reads it"); return CV_ERR_STATE; }
     a.tab_h = a.tab_w = nullptr;
     if (tab_h) {
         RelPosParams rp{};
@@ -744,7 +749,8 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
         const bool own_kv = window && b.Kw && b.Vtw;
         CVA_TRY(run_attention_layer<T>(f8 ? h->xn8 : h->xn, b.qkv, b.tab_h, b.tab_w, window, h->Q, own_kv ? b.Kw : h->K,
                                        own_kv ? b.Vtw : (window ? h->Vt_win : h->Vt_glob), h->relh, h->relw, h->attn_out, B, g.gh, g.gw,
-                                       g.has_cls, heads, D, c.window_size, st, own_kv, f8 ? h->xn_sca : nullptr, f8 ? h->xn_scw : nullptr, Mp));
+                                       g.has_cls, heads, D, c.window_size, st, own_kv, f8 ? h->xn_sca : nullptr, f8 ? h->xn_scw : nullptr, Mp,
+                                       g.v_rm));
         if (fuse_add) {
             // fp16 engine: proj writes its fp16 output (as the reference's autocast Linear does); the add into the fp32
             // residual stream rides with LayerNorm 2, which has to stream that row anyway (elementwise.hip)
@@ -1023,6 +1029,21 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
     const size_t es = esize(dt);
     const int D = c.embed_dim, heads = c.num_heads, hd = D / heads, B = g.B;
     const size_t M = (size_t)B * g.ntok;
+    if (c.arch == CV_ARCH_SAM && dt == CV_DTYPE_F16 && !h->debug) {
+        // V row-major for every block, when both the window and the global layers of this geometry run kernels that read it
+        // (the geometry test of run_attention_layer, made once here: the per-block window buffers below are pre-filled accordingly)
+        static float dummy_tab = 0.f;
+        AttnParams aw{}, ag{};
+        const int ws = c.window_size;
+        aw.S = B * g.nwy * g.nwx; aw.heads = heads; aw.L = g.Lw; aw.Lp = g.Lpw; aw.hd = hd; aw.D = D; aw.nk = g.Lw; aw.KH = ws; aw.KW = ws;
+        aw.win = ws; aw.tab_h = aw.tab_w = &dummy_tab;
+        aw.win_prep = ((size_t)aw.S * heads * g.Lw * ws * 4 >= 32768) ? (void*)&dummy_tab : nullptr;
+        ag.S = B; ag.heads = heads; ag.L = g.Lg; ag.Lp = g.Lpg; ag.hd = hd; ag.D = D; ag.nk = g.Lg; ag.KH = g.gh; ag.KW = g.gw;
+        ag.tab_h = ag.tab_w = &dummy_tab;
+        bool any_win = false, any_glob = false;
+        for (auto& b : h->blocks) { if (b.global) any_glob = true; else any_win = true; }
+        g.v_rm = ((!any_win || attn_takes_vrm(aw, 2)) && (!any_glob || attn_takes_vrm(ag, 2))) ? 1 : 0;
+    }
     int s11, s12, bott; skip_dims(c, &s11, &s12, &bott);
     auto A = [&](void** p, size_t bytes, bool zero = false) -> int {
         h->ws_bytes += bytes;
@@ -1050,7 +1071,7 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
                 CVA_TRY(A(&b.Vtw, (size_t)B * nwin * heads * hd * g.Lpw * es, true));
                 PadKVParams pk{};
                 pk.K = b.Kw; pk.Vt = b.Vtw; pk.qkv_bias = b.qkv.bias; pk.B = B; pk.heads = heads; pk.hd = hd; pk.D = D; pk.L = g.Lw;
-                pk.Lp = g.Lpw; pk.win = c.window_size; pk.gw = g.gw; pk.gh = g.gh; pk.nwx = g.nwx; pk.nwy = g.nwy;
+                pk.Lp = g.Lpw; pk.win = c.window_size; pk.gw = g.gw; pk.gh = g.gh; pk.nwx = g.nwx; pk.nwy = g.nwy; pk.v_rm = g.v_rm;
                 const int rc = !is_f32(dt) ? launch_pad_kv<half_t>(pk, nullptr) : launch_pad_kv<float>(pk, nullptr);
                 if (rc) { cva_set_error("pad_kv launch failed (%d)", rc); return CV_ERR_HIP; }
             }

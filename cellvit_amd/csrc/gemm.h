@@ -62,8 +62,10 @@ struct GemmParams {
     int ldc;
     // OUT_LINEAR row remap: orow = m + (m / o_rpi) * o_extra + o_off (o_rpi == 0: identity)
     int o_rpi, o_extra, o_off;
-    // OUT_QKV: scatter q,k -> [S*heads, L, hd], v -> V^T [S*heads, hd, Lp]
+    // OUT_QKV: scatter q,k -> [S*heads, L, hd], v -> V^T [S*heads, hd, Lp]  (v_rm != 0: v ROW-major [S*heads, L, hd] like k, into vt_out —
+    // the layout the attention kernels with a transposing LDS read consume, attention.h AttnParams::v_rm)
     void* q_out; void* k_out; void* vt_out;
+    int v_rm;
     int D, hd, heads, ntok, L, Lp;   // ntok tokens per image (incl. cls for ViT)
     int n_off;                       // OUT_QKV: column n of this launch is column n + n_off of the fused qkv projection
     int win, gw, gh, nwx, nwy;       // win > 0: window partition of the gh x gw token grid
@@ -83,6 +85,9 @@ struct GemmParams {
     int epi_vec;                     // 1: LDS-staged 16-byte epilogue stores (set by launch_gemm)
     int dbg;                         // experiment switches (CVA_GEMM_DBG): 1 no staging, 2 no LDS reads, 4 no L2 prefetch
     int stagger;                     // experiment (ablation builds, CVA_GEMM_STAGGER): start delay spread in units of 10 ns; > 0 per XCD, < 0 per workgroup
+    // 8-phase kernel, phase-shifted tile walk (gemm8.hip): fp32 scratch of 256 x 256 accumulators per workgroup, or null = every
+    // workgroup walks whole tiles in lockstep.  Filled in by launch_gemm8 for the launches that profit.
+    float* park;
 };
 
 template <typename T> int launch_gemm(const GemmParams& p, int a_mode, hipStream_t stream);
@@ -94,9 +99,6 @@ int launch_gemm8(const GemmParams& p, hipStream_t stream);
 // per gemm4_takes.  sched: slot placement variant (ablation builds; production = 1).
 bool gemm4_takes(const GemmParams& p);
 int launch_gemm4(const GemmParams& p, int sched, hipStream_t stream);
-// gemm2.hip: 256 x 128 tiles, two unsynchronised workgroups per CU (OUT_LINEAR).
-bool gemm2_supported(const GemmParams& p);
-int launch_gemm2(const GemmParams& p, hipStream_t stream);
 // fp8 engine: the same kernel on MX-fp8 operands; out_mode OUT_LINEAR (fp32 / fp16 out, optional residual), OUT_QKV or
 // OUT_MX8.  Returns hipErrorInvalidValue when the shape does not qualify (there is no fallback kernel for fp8 operands).
 bool gemm8_f8_supported(const GemmParams& p);

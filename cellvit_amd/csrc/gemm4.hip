@@ -166,7 +166,7 @@ __global__ __launch_bounds__(G4_NT) void gemm4_kernel(const GemmParams p) {
         // consecutive tiles of a workgroup share their A panel: every other tile walks K backwards (its latest slices are in L2)
         const bool rev = (tile / (int)gridDim.x) & 1;
         kstart = rev ? nk - 1 : 0; kstep = rev ? -1 : 1;
-        swap = OMODE == OUT_QKV && (n0 + p.n_off) >= 2 * p.D;          // v columns: operands exchanged (block-uniform)
+        swap = OMODE == OUT_QKV && !p.v_rm && (n0 + p.n_off) >= 2 * p.D;          // v columns: operands exchanged (block-uniform)
         const long ar0 = a_row(m0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -211,8 +211,7 @@ __global__ __launch_bounds__(G4_NT) void gemm4_kernel(const GemmParams p) {
     w_ad[0] = lds0 + G8_WOFF + (wc * 128) * 128 + off0; w_ad[1] = w_ad[0] + d1;       // + stage*32K + j*2K
 
     if ((OMODE == OUT_LINEAR) && p.act == ACT_GELU) {             // (read only in epilogues: many barriers later)
-        float* lut = reinterpret_cast<float*>(smem4 + G8_LUT);
-        for (int i = threadIdx.x; i <= G8_LUTN; i += G4_NT) lut[i] = 0.5f * (1.0f + erff((-8.0f + (float)i * (1.0f / 128.f)) * 0.70710678118654752f));
+        gelu_fill_lut(reinterpret_cast<float*>(smem4 + G8_LUT), threadIdx.x, G4_NT);
     }
 
     // ---- the K-tile stream.  The workgroup's output tiles form ONE sequence of K tiles: the last K iteration of an output

@@ -36,6 +36,17 @@
 //  wave group and L2-prefetch touches to the other is correct but 4-8 % SLOWER than no prefetch: the stalls at the
 //  counted waits are not HBM misses that a touch could turn into L2 hits.)
 //
+// Phase-shifted tile walk (OUT_LINEAR, p.park != null).  One persistent workgroup per CU and equal tiles mean that all 256 CUs reach
+// their epilogues in the same instant: the stores (and fc2's fp32 residual reads) of a whole round of tiles hit HBM as one burst while
+// every matrix pipe idles, then HBM idles while everybody computes.  Measured with a start-delay experiment (profiles/r04_a_*): spreading
+// the workgroups' epilogues over a tile period is worth 6-7 % on fc2 (512 KB of epilogue traffic per tile), 4.5 % on proj, nothing on
+// fc1 (its epilogue is GELU-VALU bound) — but a start delay pays a tile of idle tail.  Instead the workgroups of XCD x start INSIDE their
+// first tile, at K tile phi = x * nk / 8 (even): they accumulate K tiles [phi, nk) of that tile, PARK the fp32 accumulators in a private
+// scratch (256 KB per workgroup, written and later read by the same lanes — no cross-workgroup traffic, no flags), walk their
+// remaining tiles as usual, and finish with K tiles [0, phi) of the first tile on top of the parked partial sums.  Every XCD's tile
+// boundaries are thereby shifted by x / 8 of a tile period; the total number of K tiles per workgroup is unchanged, nobody idles.
+// The workgroups of one XCD stay in step with each other (they share A / W panels through that XCD's L2).
+//
 // F8 = 1: the same schedule on OCP MX-fp8 operands (e4m3 elements, one E8M0 scale per 32 K elements: BASELINE.json
 // configs[4]).  A tile row is still 128 bytes = 128 K elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 step (8 passes, twice
 // the FLOPs per cycle of the fp16 instruction), so the LDS image, the DMA, the number of fragment reads and the phase
@@ -48,6 +59,10 @@
 //     global_load_lds_dword per wave and are stored in global memory already in the order the fragment reads want them:
 //     ONE ds_read_b32 hands a lane the scales of the four fragments of a sub-tile, selected per MFMA by op_sel
 //     (layouts: mx8_scale_off_a / mx8_scale_off_w in gemm.h, written by the producers / the weight packer).
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "gemm.h"
 #include "gemm_epilogue.h"
 #include "gemm8_epi.h"
@@ -164,14 +179,25 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     // row, next columns), so every other tile walks K BACKWARDS — the panel's most recently streamed K slices are
     // still in L2 when the next tile starts from that end.
     int kstart = 0, kstep = 1;
-    auto tile_setup = [&](int tile, int& m0, int& n0, bool& swap) {
+    // Phase-shifted walk (see the header): the workgroup's tiles as a sequence of ITEMS.  phi == 0: item i = tile i, whole.
+    // phi > 0: item 0 = K tiles [phi, nk) of tile 0 (parked), items 1 .. ntl-1 = tiles 1 .. ntl-1, item ntl = K tiles [0, phi) of tile 0.
+    constexpr bool PSHIFT = OMODE == OUT_LINEAR && TRANS == 1 && !F8 && !CV3 && ABL == 0;
+    const int ntl = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    int phi = 0;
+    if (PSHIFT && p.park && ntl >= 2) phi = ((((int)blockIdx.x & 7) * nk) >> 3) & ~1;
+    const int nitems = ntl + (phi ? 1 : 0);
+    int kcnt_next = nk;                 // K tiles of the item whose DMA is issued next (even, >= 2)
+    auto tile_setup = [&](int item, int& m0, int& n0, bool& swap) {
         int tm, tn;
+        const int tile = (int)blockIdx.x + ((phi && item == ntl) ? 0 : item) * (int)gridDim.x;
         tile_coords(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
         m0 = tm * G8_BM; n0 = tn * G8_BN;
-        const bool rev = ((tile / (int)gridDim.x) & 1) && !(p.dbg & 128);
-        kstart = rev ? nk - 1 : 0; kstep = rev ? -1 : 1;
+        const bool rev = (item & 1) && !(p.dbg & 128);
+        kstart = rev ? nk - 1 : 0; kstep = rev ? -1 : 1; kcnt_next = nk;
+        if (phi && item == 0) { kstart = phi; kstep = 1; kcnt_next = nk - phi; }
+        if (phi && item == ntl) { kstart = 0; kstep = 1; kcnt_next = phi; }
         // v columns of the fused qkv projection: exchange the operands (see epilogue8_vt); block-uniform
-        swap = OMODE == OUT_QKV && TRANS == 1 && (n0 + p.n_off) >= 2 * p.D;
+        swap = OMODE == OUT_QKV && TRANS == 1 && !p.v_rm && (n0 + p.n_off) >= 2 * p.D;
         if (COMP) {
             const int pim = m0 & (p.H * p.Wd - 1);
             const int par = n0 / (p.N >> 2);
@@ -441,11 +467,10 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     // ---- persistent loop over output tiles: the DMA of tile t+1's first two K tiles is issued BEFORE tile t's
     // epilogue, so its latency (and the epilogue's store drain) overlap instead of adding up
     if (TRANS && (OMODE == OUT_LINEAR || OMODE == OUT_MX8) && p.act == ACT_GELU) {     // (read only in epilogues: many barriers later)
-        float* lut = reinterpret_cast<float*>(smem8 + G8_LUT);
-        for (int i = threadIdx.x; i <= G8_LUTN; i += G8_NT) lut[i] = 0.5f * (1.0f + erff((-8.0f + (float)i * (1.0f / 128.f)) * 0.70710678118654752f));
+        gelu_fill_lut(reinterpret_cast<float*>(smem8 + G8_LUT), threadIdx.x, G8_NT);
     }
     int m0, n0; bool swap;
-    int tile = blockIdx.x;
+    int item = 0;
     int slot = 0;
 #ifdef CVA_ABLATION
     if (p.stagger) {       // experiment: de-phase the workgroups' epilogues (stores of all CUs otherwise hit HBM in the same instant)
@@ -455,9 +480,10 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         while ((long)wall_clock64() - t0 < target) __builtin_amdgcn_s_sleep(16);
     }
 #endif
-    tile_setup(tile, m0, n0, swap);
+    tile_setup(item, m0, n0, swap);
     stage_prologue(n0, swap, slot);
-    for (; tile < ntiles; tile += gridDim.x, slot ^= 1) {
+    for (; item < nitems; ++item, slot ^= 1) {
+        const int nk_it = kcnt_next;                // K tiles of THIS item (tile_setup moves on to the next item before the epilogue)
         f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -484,8 +510,8 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             G8_VMCNT(4);                            // E (tile + its scale blocks) has landed; O.W may still be in flight
             G8_BAR8();
             if (wr == 1) G8_BAR8();                 // stagger the second wave group by one barrier
-            for (int kt = 0; kt < nk; kt += 2) {
-                const bool more = kt + 2 < nk;      // block-uniform
+            for (int kt = 0; kt < nk_it; kt += 2) {
+                const bool more = kt + 2 < nk_it;   // block-uniform
                 // ---- phase 1
                 G8F_RD_A(F0, sA0, 0, 0); G8F_RD_W(FX, 0, 0); G8F_RD_SW(sWE, 0);
                 stage_a(1, kt + 1);
@@ -519,8 +545,8 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }
         if (wr == 1) G8_BAR();                      // stagger the second wave group by one barrier
 
-        for (int kt = 0; kt < nk; kt += 2) {
-            const bool more = kt + 2 < nk;          // block-uniform
+        for (int kt = 0; kt < nk_it; kt += 2) {
+            const bool more = kt + 2 < nk_it;       // block-uniform
             // ---- phase 1
             if (!no_rd) G8_RD_W(Y, 0, 1);
             G8_BAR(); G8_MMQ(4, A0, X, 0, 0); G8_BAR();
@@ -553,7 +579,8 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         if (wr == 0) G8_BAR();                      // re-align the wave groups: every LDS read has retired
 
         const int em0 = m0, en0 = n0; const bool eswap = swap;
-        const bool has_next = tile + (int)gridDim.x < ntiles;
+        const bool has_next = item + 1 < nitems;
+        const bool park_it = PSHIFT && phi && item == 0, unpark_it = PSHIFT && phi && item == ntl;
         // bias of this lane's outputs from the tile's LDS slot (staged with the tile's first DMA group)
         float bv[16];
         if (TRANS) {
@@ -574,8 +601,33 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         // load issued behind the DMA group could only be consumed once the whole group had landed).
         const bool dma_first = TRANS && has_next && !(OMODE == OUT_LINEAR && p.res) && !(p.dbg & 16);
         if (dma_first) {                            // direct epilogues do not touch LDS: start the next tile's DMA first
-            tile_setup(tile + gridDim.x, m0, n0, swap);
+            tile_setup(item + 1, m0, n0, swap);
             stage_prologue(n0, swap, slot ^ 1);
+        }
+        if constexpr (PSHIFT) {
+            // lane-linear scratch image [wave][fragment][lane] of f32x4: every instruction moves 1 KiB; written and read by the same lanes
+            if (park_it) {                          // K tiles [phi, nk) of the first tile: keep the partial sums, no epilogue
+                int lo = lane * 4;                  // (opaque: the 32 addresses below are loop invariant and would be hoisted out of the
+                asm volatile("" : "+v"(lo));        //  item loop into 64 spilled VGPRs)
+                float* pk = p.park + ((size_t)blockIdx.x * 256 + (size_t)wave * 32) * 256 + lo;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(pk + (i * 4 + j) * 256));
+                if (has_next && !dma_first) { tile_setup(item + 1, m0, n0, swap); stage_prologue(n0, swap, slot ^ 1); }
+                continue;
+            }
+        }
+        // last item of a phase-shifted walk (no DMA in flight): K tiles [0, phi) + the parked partial sums, which the epilogue adds
+        // to its per-row temporaries (the accumulators themselves are never modified outside the K loop: a conditional update of
+        // all 128 of them made the register allocator keep two copies — 72 spilled VGPRs around EVERY epilogue)
+        const float* parked = nullptr;
+        if constexpr (PSHIFT) {
+            if (unpark_it) {
+                int lo = lane * 4;
+                asm volatile("" : "+v"(lo));
+                parked = p.park + ((size_t)blockIdx.x * 256 + (size_t)wave * 32) * 256 + lo;
+            }
         }
         if (no_epi) {      // experiment: keep the accumulators live, one store per lane
             float t = 0.f;
@@ -584,12 +636,12 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
             reinterpret_cast<half_t*>(p.out)[(long)(em0 + wr * 128 + (lane >> 4)) * p.ldc + en0 + wc * 64 + (lane & 15)] = (half_t)t;
-            if (has_next && !dma_first) { tile_setup(tile + gridDim.x, m0, n0, swap); stage_prologue(n0, swap, slot ^ 1); }
+            if (has_next && !dma_first) { tile_setup(item + 1, m0, n0, swap); stage_prologue(n0, swap, slot ^ 1); }
         } else if (TRANS) {
             if (eswap) epilogue8_vt(p, acc, bv, en0 + wr * 128, em0 + wc * 64, lane);
-            else epilogue8_direct<OMODE>(p, acc, bv, em0 + wr * 128, en0 + wc * 64, lane, reinterpret_cast<const float*>(smem8 + G8_LUT));
+            else epilogue8_direct<OMODE>(p, acc, bv, em0 + wr * 128, en0 + wc * 64, lane, reinterpret_cast<const float*>(smem8 + G8_LUT), parked);
             if (has_next && !dma_first) {
-                tile_setup(tile + gridDim.x, m0, n0, swap);
+                tile_setup(item + 1, m0, n0, swap);
                 stage_prologue(n0, swap, slot ^ 1);
             }
         } else {
@@ -598,11 +650,30 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             if (has_next) {                         // staged epilogue used LDS: fence it before the next tile's DMA
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 G8_BAR();
-                tile_setup(tile + gridDim.x, m0, n0, swap);
+                tile_setup(item + 1, m0, n0, swap);
                 stage_prologue(n0, swap, slot ^ 1);
             }
         }
     }
+}
+
+// Scratch of the phase-shifted walk: 256 KB per workgroup, one buffer per stream (launches of one stream are ordered; the forward
+// runs all its GEMMs on one stream).  Allocated on first use, kept for the life of the process.
+float* park_scratch(hipStream_t stream, int grid) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, std::pair<float*, int>> ws;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& e = ws[{dev, stream}];
+    if (e.second < grid) {
+        if (e.first) (void)hipFree(e.first);
+        e.first = nullptr; e.second = 0;
+        void* q = nullptr;
+        if (hipMalloc(&q, (size_t)grid * 256 * 256 * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        e.first = reinterpret_cast<float*>(q); e.second = grid;
+    }
+    return e.first;
 }
 
 template <int OMODE, int TRANS, int ABL, int F8 = 0, int CV3 = 0>
@@ -622,6 +693,20 @@ int launch8(const GemmParams& p, hipStream_t stream) {
     }
     const int tiles = (p.M / G8_BM) * (p.N / G8_BN);
     const int grid = (tiles < n_cu || (p.dbg & 32)) ? tiles : n_cu;   // persistent: one workgroup per CU walks tiles grid-stride
+    if (OMODE == OUT_LINEAR && TRANS == 1 && !F8 && !CV3 && ABL == 0) {
+        // Phase-shifted walk (file header) where the epilogue moves many bytes per tile: fp32 output / fp32 residual (fc2: 512 KB per
+        // tile).  Same-call A/B (profiles/r04_b_gemm_phase_shift.txt, M = 262144): fc2 3255 -> 3204 us (-1.6 %), proj 930 -> 932 (0),
+        // fc1 3159 -> 3181 (+0.7 %: its GELU epilogue is VALU bound, the park / unpark traffic is pure cost) — so fc2-like launches only.
+        // Needs >= 2 tiles per workgroup and >= 8 K tiles.
+        GemmParams q = p;
+        static const int mode = cva_env_int("CVA_GEMM_PHASE", -1);       // ablation builds: 0 off, 1 every OUT_LINEAR launch, -1 heuristic
+        const int nk = p.K / G8_BK;
+        bool want = p.out_f32 || p.res;
+        if (mode == 0) want = false; else if (mode == 1) want = true;
+        q.park = (want && tiles >= 2 * grid && nk >= 8 && grid % 8 == 0) ? park_scratch(stream, grid) : nullptr;
+        hipLaunchKernelGGL((gemm8_kernel<OMODE, TRANS, ABL, F8, CV3>), dim3(grid), dim3(G8_NT), G8_LDS, stream, q);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL((gemm8_kernel<OMODE, TRANS, ABL, F8, CV3>), dim3(grid), dim3(G8_NT), G8_LDS, stream, p);
     return (int)hipGetLastError();
 }
@@ -697,7 +782,7 @@ int launch_gemm8_deconv(const GemmParams& p_in, hipStream_t stream) {
 bool gemm8_f8_supported(const GemmParams& p) {
     if (p.M % G8_BM || p.N % G8_BN || p.K % 256 || p.K < 256) return false;             // K tiles of 128 elements, two per iteration
     if (((size_t)p.A & 15) || ((size_t)p.W & 15) || (p.lda % 16) || (p.ldw % 16) || p.lda < p.K || p.ldw < p.K) return false;
-    if (p.a_rpi || !p.a_scale || !p.w_scale) return false;
+    if (p.a_rpi || !p.a_scale || !p.w_scale || p.v_rm) return false;      // (fp8 V tiles run swapped: V^T only)
     if (((size_t)p.a_scale & 3) || ((size_t)p.w_scale & 3)) return false;
     if (256L * p.lda >= (1L << 31) || 256L * p.ldw >= (1L << 31)) return false;               // 32-bit lane offsets inside a tile
     if (p.out_mode == OUT_QKV && (p.D % G8_BN || p.hd % 16 || p.N != 3 * p.D || p.n_off || !p.a_scale_w)) return false;
@@ -719,8 +804,6 @@ int launch_gemm8(const GemmParams& p, hipStream_t stream) {
 #ifdef CVA_ABLATION
     {   // experiment (ablation builds): CVA_GEMM4 = 10 + s runs the one-wave-per-SIMD kernel of gemm4.hip with slot placement s, 30 + a its
         // work-skipping instantiations.  Measured slower than this kernel (profiles/r03_exp_gemm4.txt), so production never routes there.
-        static const int g2 = cva_env_int("CVA_GEMM2", 0);
-        if (g2 && !(p.dbg & 7) && gemm2_supported(p)) return launch_gemm2(p, stream);
         static const int g4 = cva_env_int("CVA_GEMM4", 0);
         if (g4 >= 10 && !(p.dbg & 7) && gemm4_takes(p)) return launch_gemm4(p, g4 - 10, stream);
     }

@@ -14,9 +14,9 @@ constexpr int G8_BM = 256, G8_BN = 256, G8_BK = 64, G8_NT = 512;
 constexpr int G8_TILE = 256 * 128;          // bytes of one A or W tile (256 rows x 128 B)
 constexpr int G8_WOFF = 2 * G8_TILE;        // LDS layout: [E.A][O.A][E.W][O.W] -> buffer select = +32 KiB immediate offset
 constexpr int G8_BIAS = 4 * G8_TILE;       // two 1-KiB bias slots (256 floats each, alternating per output tile)
-constexpr int G8_LUT = 4 * G8_TILE + 2048;  // GELU: Phi(x) at x = -8 + i/128, i = 0 .. 2048 (fp32), filled once per workgroup
+constexpr int G8_LUT = 4 * G8_TILE + 2048;  // GELU: pairs (Phi(x_i), Phi'(x_i) / 128) at x_i = -8 + i/128, i = 0 .. 2048 (fp32), filled once per workgroup
 constexpr int G8_LUTN = 2048;
-constexpr int G8_SC = G8_LUT + (G8_LUTN + 1) * 4 + 12;      // F8: scale images, [E | O] x [A-side 1 KiB | W-side 1 KiB]
+constexpr int G8_SC = G8_LUT + (G8_LUTN + 1) * 8 + 8;       // F8: scale images, [E | O] x [A-side 1 KiB | W-side 1 KiB]
 constexpr int G8_LDS = G8_SC + 4096;
 
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
@@ -48,17 +48,37 @@ __device__ __forceinline__ float gelu_as(float x) {
     return x >= 0.f ? x - q : q;
 }
 
-// GELU on the 8-phase path: x * Phi(x) with Phi linearly interpolated in the LDS table (h = 1/128: |dPhi| <= h^2/8 |x phi(x)|
-// < 1.9e-6 absolute and < 2e-4 relative everywhere, i.e. below half an fp16 ulp of the result); 8 full-rate VALU + one
-// ds_read2_b32 per element instead of 12 + rcp + exp.  x <= -8 -> x * 6e-16, x >= 8 -> x.
-template <int PER_UNIT = 128>     // table entries per unit of x; the table spans x = -8 .. 8 (16 * PER_UNIT + 1 entries)
-__device__ __forceinline__ float gelu_lut(float x, const float* lut) {
-    float u = fmaf(x, (float)PER_UNIT, 8.f * PER_UNIT);
-    u = __builtin_amdgcn_fmed3f(u, 0.f, 16.f * PER_UNIT - 0.001f);
-    const float fr = __builtin_amdgcn_fractf(u);
-    const int i = (int)u;
-    const float t0 = lut[i], t1 = lut[i + 1];
-    return x * fmaf(fr, t1 - t0, t0);
+// GELU on the 8-phase path: x * Phi(x) from a table in LDS, h = 1/128 over x = -8 .. 8 (|dPhi| <= h^2/8 |x phi(x)| < 1.9e-6 absolute and
+// < 2e-4 relative everywhere, i.e. below half an fp16 ulp of the result).  x <= -8 -> x * 6e-16, x >= 8 -> x.  (Rounds 2-3: chord
+// interpolation between the two neighbouring nodes, 7 VALU + one ds_read2_b32 per element.)
+// Round 4: the same table read at the NEAREST node with the first derivative (Taylor instead of chord: the same h^2/8 |Phi''| bound,
+// measured 2.3e-6 abs / 1.3e-4 rel against 2.4e-6 / 1.3e-4), two elements per instruction where a packed fp32 form exists (the
+// epilogue runs no MFMAs, so the packed instructions cost nothing extra here).  u = 128 x + 1024 is rounded to the nearest integer by
+// adding 1.5 * 2^23: the float's low mantissa bits ARE the node index (bits = 0x4B400000 + i), so the LDS byte address of the pair is
+// one v_lshl_add_u32 of the raw bits; the fraction is 128 x + (1024 + 1.5 * 2^23 - t), exact.  Per element: 1 clamp + 1 address +
+// 4 packed halves (t, c, fr, Phi) + the final multiply (half) = 4.5 VALU + one ds_read_b64, against 7 + ds_read2_b32 before.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_fill_lut(float* lut, int tid, int nthreads) {        // lut: (G8_LUTN + 1) pairs
+    for (int i = tid; i <= G8_LUTN; i += nthreads) {
+        const float x = -8.0f + (float)i * (1.0f / 128.f);
+        lut[2 * i] = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        lut[2 * i + 1] = expf(-0.5f * x * x) * (0.3989422804014327f / 128.f);
+    }
+}
+__device__ __forceinline__ f32x2_t gelu_lut_pair(const f32x2_t x, const unsigned lut_lds /* LDS byte address of the table */) {
+    constexpr float MAGIC = 12582912.0f;                         // 1.5 * 2^23
+    f32x2_t xc;
+    xc[0] = __builtin_amdgcn_fmed3f(x[0], -8.0f, 7.996f); xc[1] = __builtin_amdgcn_fmed3f(x[1], -8.0f, 7.996f);
+    const f32x2_t k128 = {128.f, 128.f}, kb = {1024.f + MAGIC, 1024.f + MAGIC};
+    const f32x2_t t = __builtin_elementwise_fma(xc, k128, kb);   // MAGIC + round(128 x + 1024)
+    const unsigned a0 = (__float_as_uint(t[0]) << 3) + (lut_lds - (0x4B400000u << 3));
+    const unsigned a1 = (__float_as_uint(t[1]) << 3) + (lut_lds - (0x4B400000u << 3));
+    typedef const __attribute__((address_space(3))) f32x2_t* lp;
+    const f32x2_t e0 = *(lp)(unsigned long)a0, e1 = *(lp)(unsigned long)a1;       // (Phi, Phi' / 128) of the two nodes
+    const f32x2_t c = kb - t;                                    // exact
+    const f32x2_t fr = __builtin_elementwise_fma(xc, k128, c);   // in [-0.5, 0.5]
+    const f32x2_t T = {e0[0], e1[0]}, D = {e0[1], e1[1]};
+    return x * __builtin_elementwise_fma(fr, D, T);
 }
 
 // Direct epilogue for the TRANSPOSED accumulator orientation (C^T fragments: lane (g, li) holds, for row
@@ -66,7 +86,10 @@ __device__ __forceinline__ float gelu_lut(float x, const float* lut) {
 // time to make them consecutive).  No LDS: bias / activation / residual on registers, 16-byte stores.
 template <int OMODE, int LUT_PER_UNIT = 128>
 __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&acc)[8][4], const float (&bv)[16],
-                                                 const int mrow0, const int ncol0, const int lane, const float* lut) {
+                                                 const int mrow0, const int ncol0, const int lane, const float* lut,
+                                                 const float* parked = nullptr) {
+    // parked: partial sums of this lane's fragments from an earlier pass over the same tile (gemm8.hip, phase-shifted walk), f32x4
+    // [fragment i * 4 + j] at a stride of 256 floats, added BEFORE bias / activation; null for ordinary tiles
     const int g = lane >> 4, li = lane & 15;
     const int n = ncol0 + g * 16;
     if (p.n_valid && n >= p.n_valid) return;            // padded columns (no cross-lane operation below: OUT_MX8 never runs padded)
@@ -77,7 +100,7 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
         const int which = nn / p.D;
         const int c = nn - which * p.D;
         const int h = c / p.hd, d = c - h * p.hd;           // 16 consecutive d inside one head (hd % 16 == 0)
-        qk = reinterpret_cast<half_t*>(which == 0 ? p.q_out : p.k_out);
+        qk = reinterpret_cast<half_t*>(which == 0 ? p.q_out : (which == 1 ? p.k_out : p.vt_out));         // which == 2: row-major v (p.v_rm)
         col_term = (long)h * p.L * p.hd + d;
     }
     // OUT_QKV: token m -> (image b, token t, grid row gy, grid col gx), advanced by 16 tokens per fragment row without
@@ -104,21 +127,34 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
     for (int i = 0; i < 8; ++i) {
         const int m = mrow0 + i * 16 + li;
         float v[16];
+        f32x4 a[4];
+        if (parked) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = acc[i][j] + __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(parked + (i * 4 + j) * 256));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = acc[i][j];
+        }
         if (p.act == ACT_GELU) {                        // (uniform branches: one activation's code per launch, no selects)
+            const unsigned lut_lds = (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)lut;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[j * 4 + r] = gelu_lut<LUT_PER_UNIT>(acc[i][j][r] + bv[j * 4 + r], lut);
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2_t xin = {a[j][r] + bv[j * 4 + r], a[j][r + 1] + bv[j * 4 + r + 1]};
+                    const f32x2_t y = gelu_lut_pair(xin, lut_lds);
+                    v[j * 4 + r] = y[0]; v[j * 4 + r + 1] = y[1];
+                }
         } else if (p.act == ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaxf(acc[i][j][r] + bv[j * 4 + r], 0.f);
+                for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaxf(a[j][r] + bv[j * 4 + r], 0.f);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] + bv[j * 4 + r];
+                for (int r = 0; r < 4; ++r) v[j * 4 + r] = a[j][r] + bv[j * 4 + r];
         }
         if (OMODE == OUT_LINEAR) {
             long orow = m;

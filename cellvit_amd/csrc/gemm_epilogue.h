@@ -33,7 +33,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             const int c = n + p.n_off - which * p.D;
             const int h = c / p.hd, d = c - h * p.hd;
             // q,k: ((s*heads+h)*L + pos)*hd + d ; vt: ((s*heads+h)*hd + d)*Lp + pos
-            col_term = (which < 2) ? ((long)h * p.L * p.hd + d) : (((long)h * p.hd + d) * p.Lp);
+            col_term = (which < 2 || p.v_rm) ? ((long)h * p.L * p.hd + d) : (((long)h * p.hd + d) * p.Lp);
         } else if (OMODE == OUT_CONVT) {
             const int cout = p.N >> 2;
             const int dd = n / cout, co = n - dd * cout;
@@ -77,6 +77,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     const T tv = TR::from_float(v);
                     if (which == 0) reinterpret_cast<T*>(p.q_out)[((long)s * p.heads * p.L + pos) * p.hd + col_term] = tv;
                     else if (which == 1) reinterpret_cast<T*>(p.k_out)[((long)s * p.heads * p.L + pos) * p.hd + col_term] = tv;
+                    else if (p.v_rm) reinterpret_cast<T*>(p.vt_out)[((long)s * p.heads * p.L + pos) * p.hd + col_term] = tv;
                     else reinterpret_cast<T*>(p.vt_out)[(long)s * p.heads * p.hd * p.Lp + col_term + pos] = tv;
                 }
             }
@@ -106,7 +107,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     // OUT_QKV: a 64-column wave slab lies inside one of q / k / v (D % 64 == 0)
     int which = 0;
     if (OMODE == OUT_QKV) which = (col0 + p.n_off) / p.D;
-    const bool vt_slab = OMODE == OUT_QKV && which == 2;
+    const bool vt_slab = OMODE == OUT_QKV && which == 2 && !p.v_rm;
 
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -208,7 +209,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
                         s_ = (b * p.nwy + wy) * p.nwx + wx;
                         pos = (gy - wy * p.win) * p.win + (gx - wx * p.win);
                     }
-                    outT = reinterpret_cast<T*>(which == 0 ? p.q_out : p.k_out);
+                    outT = reinterpret_cast<T*>(which == 0 ? p.q_out : (which == 1 ? p.k_out : p.vt_out));       // (which == 2: row-major v)
                     o = (((long)s_ * p.heads + h) * p.L + pos) * p.hd + d;
                 }
                 // T output: 8 elements
