@@ -62,6 +62,8 @@ SYMBOLS = {
                                    C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cv_op_layernorm_mx8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "cv_geometry_flags": (C.c_int, [C.c_void_p]),
+    "cv_op_attention_rows_mx8": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_void_p]),
     "cv_op_attention_mx8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cv_set_debug": (C.c_int, [C.c_void_p, C.c_int]),

@@ -459,6 +459,9 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             row = (long)s_idx * p.ntok + qg;
         }
         const float inv = 1.0f / lsum;
+        if constexpr (sizeof(T) == 2 && HD == 80) {
+            if (p.out8) { attn_store_mx8(p, o[qb], inv, row, h, g); continue; }      // fp8 engine: MX-fp8 rows for the proj GEMM
+        }
 #pragma unroll
         for (int n = 0; n < ND; ++n) {
             typename Pack4<T>::type v;
@@ -489,13 +492,16 @@ int launch_attn2_impl(const AttnParams& p, hipStream_t stream) {
 
 template <typename T, int HD>
 int launch_attn2_hd(const AttnParams& p, hipStream_t stream) {
-    if (p.v_rm) {      // row-major V: fp16, hd 80 only (attn_takes_vrm)
+    if (p.v_rm) {      // row-major V: fp16, hd 80 only; measured slower than V^T for this kernel (profiles/r04_d_vrm_kernels.txt), so the
+                       // instantiations exist in ablation builds only (CVA_VRM_GLOBAL=1) and production never asks (attn_takes_vrm)
+#ifdef CVA_ABLATION
         if constexpr (sizeof(T) == 2 && HD == 80) {
             if (!p.tab_h) return launch_attn2_impl<T, HD, 0, 1, 1>(p, stream);
             if (p.KW == KT && p.KH <= 64 && p.nk == p.KH * p.KW) return launch_attn2_impl<T, HD, 2, 1, 1>(p, stream);
             if (p.KH + p.KW <= 32) return launch_attn2_impl<T, HD, 1, 1, 1>(p, stream);
             if (p.KH + p.KW <= 64) return launch_attn2_impl<T, HD, 1, 2, 1>(p, stream);
         }
+#endif
         return (int)hipErrorInvalidValue;
     }
     if (!p.tab_h) return launch_attn2_impl<T, HD, 0, 1>(p, stream);

@@ -396,11 +396,14 @@ struct AttnwpGeom {
     }
 };
 
-// VRM = 1 (AttnParams::v_rm, hd 80): V arrives ROW-major [L][HD] like K.  Its LDS image is then the item's V rows as they lie in
-// memory (208 rows x 160 B, DMA'd like K — no register staging, no transposing LDS stores), and the PV operand comes out of
-// ds_read_b64_tr_b16 (see attention2.hip).  One V image: the DMA of item i's V is issued at the top of item i (the image was released
-// by the barrier that ends item i-1) and has the relcat + S^T phase to land; a barrier after S^T publishes it (two barriers per item,
-// as before).
+// VRM != 0 (AttnParams::v_rm, hd 80): V arrives ROW-major [L][HD] like K.  Its LDS image is then the item's V rows as they lie in
+// memory (208 rows x 160 B, linear), and the PV operand comes out of ds_read_b64_tr_b16 (see attention2.hip).
+//   VRM = 2 (production): V by LDS-DMA like K — no register staging, no LDS stores by the waves.  Only ONE V image fits next to the two K
+//     images, so item i's V is requested at the top of item i (the image was released by the barrier that ends item i-1), has the
+//     relcat + S^T phase to land and is published by a barrier behind S^T (two barriers per item, as before);
+//   VRM = 1 (ablation builds, CVA_VRM_REG=1): the pieces of item i+1's V are requested into registers while item i computes and written
+//     to the image with five ds_write_b128 per thread at the top of item i+1 (the structure of the V^T form).
+//   Same box, same call (profiles/r04_e_vrm_window_variants.txt): V^T 1085.5 us per launch of 64 tiles, VRM 1 1052.2, VRM 2 1022.6.
 typedef __fp16 w_fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ half8_t w_frag_tr_2x4(const half_t* p0, const half_t* p1) {
     typedef __attribute__((address_space(3))) w_fp16x4_t* lp;
@@ -478,8 +481,8 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
     // nk hold finite data that only meets P = 0)
     constexpr int NDMAV = (WKEYS * GM::KPPR + 63) / 64;  // 33 for hd 80
     constexpr int DPWV = (NDMAV + 7) / 8;
-    unsigned vvoff[VRM ? DPWV : 1];
-    if constexpr (VRM) {
+    unsigned vvoff[VRM == 2 ? DPWV : 1];
+    if constexpr (VRM == 2) {
 #pragma unroll
         for (int t = 0; t < DPWV; ++t) {
             int j = (wave + 8 * t) * 64 + lane;
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         }
     }
     auto dma_v = [&](int sh) {
-        if constexpr (VRM) {
+        if constexpr (VRM == 2) {
             const unsigned char* base = uniform_ptr_w(Vb + (long)sh * p.L * HD);
 #pragma unroll
             for (int t = 0; t < DPWV; ++t) {
@@ -501,14 +504,25 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         }
     };
     constexpr int VPPR = WKEYS / PE;                    // 26 pieces per V^T row
-    constexpr int VN = VRM ? 1 : (HD * VPPR + PNT - 1) / PNT;
+    constexpr int VNR = (WKEYS * GM::KPPR + PNT - 1) / PNT;          // VRM = 1: pieces of the linear image per thread (5)
+    constexpr int VN = VRM == 2 ? 1 : (VRM == 1 ? VNR : (HD * VPPR + PNT - 1) / PNT);
     Piece vreg[VN];
     half8_t qf[2][NKS];
     const int q0 = wave * WQW;
     const bool wave_active = q0 < p.L;
 
     auto load_v = [&](int sh) {
-        if constexpr (VRM) return;
+        if constexpr (VRM == 2) return;
+        if constexpr (VRM == 1) {      // piece i of the image <- source piece min(i, nk * KPPR - 1): rows past nk hold finite data that meets P = 0
+            const half_t* __restrict__ Vg = Vb + (long)sh * p.L * HD;
+#pragma unroll
+            for (int u = 0; u < VN; ++u) {
+                int i = tid + u * PNT;
+                i = i < p.nk * GM::KPPR ? i : p.nk * GM::KPPR - 1;
+                vreg[u] = load_piece(Vg + (long)i * PE);
+            }
+            return;
+        }
         const half_t* __restrict__ Vg = Vb + (long)sh * HD * p.Lp;
 #pragma unroll
         for (int u = 0; u < VN; ++u) {
@@ -518,7 +532,15 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         }
     };
     auto store_v = [&]() {
-        if constexpr (VRM) return;
+        if constexpr (VRM == 2) return;
+        if constexpr (VRM == 1) {
+#pragma unroll
+            for (int u = 0; u < VN; ++u) {
+                const int i = tid + u * PNT;
+                if (i < WKEYS * GM::KPPR) store_piece(Vts + i * PE, vreg[u]);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < VN; ++u) {
             const int i = tid + u * PNT;
@@ -560,7 +582,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
     for (; it < nitems; it += gridDim.x, buf ^= 1) {
         const half_t* Ks = Ks0 + buf * GM::KIMG;
         const int nxt = it + gridDim.x;
-        if constexpr (VRM) {
+        if constexpr (VRM == 2) {
             // (every wave is past the barrier that ended the previous item: the V image and K image buf ^ 1 are free)
             dma_v(it);                                  // lands during the relcat + S^T phase; published by the barrier behind S^T
             if (nxt < nitems) dma_k(nxt, buf ^ 1);
@@ -654,7 +676,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                     __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs between their wait and the ring refill
                 });
             }
-            if constexpr (VRM) {                        // this wave's share of V(it) (and of K(next)) has landed; then everybody's
+            if constexpr (VRM == 2) {                   // this wave's share of V(it) (and of K(next)) has landed; then everybody's
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -777,6 +799,9 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                 } else {
                     row = (long)s_idx * p.ntok + qg;
                 }
+                if constexpr (HD == 80) {
+                    if (p.out8) { attn_store_mx8(p, o[qb], inv_l[qb], row, h, g); continue; }   // fp8 engine: MX-fp8 rows for the proj GEMM
+                }
 #pragma unroll
                 for (int n = 0; n < ND; ++n) {
                     half4_t v;
@@ -787,7 +812,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if constexpr (VRM) __builtin_amdgcn_s_barrier();   // the barrier behind the active waves' S^T phase
+            if constexpr (VRM == 2) __builtin_amdgcn_s_barrier();   // the barrier behind the active waves' S^T phase
         }
         __syncthreads();                                // every wave is done with this item's K / V^T; the next K image has landed
     }
@@ -849,12 +874,19 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
             if constexpr (HD == 80 && BIAS) {
                 static bool attr_v = false;
                 if (!attr_v) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attnwp_kernel<HD, BIAS, 1>),
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attnwp_kernel<HD, BIAS, 2>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e == hipSuccess && CVA_ABLATION_BUILD)
+                        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attnwp_kernel<HD, BIAS, CVA_ABLATION_BUILD ? 1 : 2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     if (e != hipSuccess) return (int)e;
                     attr_v = true;
                 }
-                hipLaunchKernelGGL((attnwp_kernel<HD, BIAS, 1>), dim3(items < n_cu ? items : n_cu), dim3(PNT), ldsp, stream, p);
+                static const int vreg = cva_env_int("CVA_VRM_REG", 0);      // ablation builds: the register-prefetch form of the V image, for A/B
+                if (CVA_ABLATION_BUILD && vreg)
+                    hipLaunchKernelGGL((attnwp_kernel<HD, BIAS, CVA_ABLATION_BUILD ? 1 : 2>), dim3(items < n_cu ? items : n_cu), dim3(PNT), ldsp, stream, p);
+                else
+                    hipLaunchKernelGGL((attnwp_kernel<HD, BIAS, 2>), dim3(items < n_cu ? items : n_cu), dim3(PNT), ldsp, stream, p);
                 return (int)hipGetLastError();
             }
             return (int)hipErrorInvalidValue;
@@ -862,7 +894,7 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
         hipLaunchKernelGGL((attnwp_kernel<HD, BIAS>), dim3(items < n_cu ? items : n_cu), dim3(PNT), ldsp, stream, p);
         return (int)hipGetLastError();
     }
-    if (p.v_rm) return (int)hipErrorInvalidValue;        // the other window kernels read V^T
+    if (p.v_rm || p.out8) return (int)hipErrorInvalidValue;        // the other window kernels read V^T and write fp16
     dim3 grid(p.S * p.heads);                            // one workgroup per (sequence, head); <= 2 query passes inside
     hipLaunchKernelGGL((attnw_kernel<HD, BIAS>), grid, dim3(WNT), lds, stream, p);
     return (int)hipGetLastError();
@@ -882,6 +914,18 @@ int launch_attention_win(const AttnParams& p_in, hipStream_t stream) {
     return -1;
 }
 
+// (attention.h) fp8 output: the kernels with the MX-fp8 epilogue are attnwp_kernel<80, 1, *> and attn2_kernel<half, 80, *>
+bool attn_takes_out8(const AttnParams& p) {
+    static const int persistent = cva_env_int("CVA_ATTNW_P", 1), variant = cva_env_int("CVA_ATTN", 3);
+    if (p.hd != 80 || !persistent || variant != 3) return false;
+    const bool bias = p.tab_h && p.tab_w;
+    const bool short_seq = p.nk <= WKEYS && p.nk == p.L && p.Lp >= WKEYS &&
+                           !(bias && (p.KH > 16 || p.KW > 16 || p.nk != p.KH * p.KW || !p.win_prep));
+    if (short_seq) return bias && p.nk > (WNKB - 1) * 16 && p.S * p.heads >= 64;
+    if (!bias) return true;
+    return (p.KW == 64 && p.KH <= 64 && p.nk == p.KH * p.KW) || p.KH + p.KW <= 64;
+}
+
 // (attention.h) the geometry test the dispatcher of cellvit_abi.hip makes, for the row-major V forms of the two production kernels
 bool attn_takes_vrm(const AttnParams& p, size_t elem_size) {
     static const int persistent = cva_env_int("CVA_ATTNW_P", 1), variant = cva_env_int("CVA_ATTN", 3), off = cva_env_int("CVA_NO_VRM", 0);
@@ -891,7 +935,11 @@ bool attn_takes_vrm(const AttnParams& p, size_t elem_size) {
     const bool short_seq = p.nk <= WKEYS && p.nk == p.L && p.Lp >= WKEYS &&
                            !(bias && (p.KH > 16 || p.KW > 16 || p.nk != p.KH * p.KW || !p.win_prep));
     if (short_seq) return bias && p.nk > (WNKB - 1) * 16 && p.S * p.heads >= 64;
-    // everything else runs attn2_kernel (or falls through to v1 when its bias forms do not fit)
+    // Everything else runs attn2_kernel, whose row-major form (ablation builds) is SLOWER: 10.06 against
+    // 9.19 ms per global SAM-H launch of 64 tiles (profiles/r04_d_vrm_kernels.txt: two ds_read_b64_tr_b16 per fragment instead of one
+    // ds_read2_b64), while the qkv projection of a global layer already writes V^T with 16-byte stores.  Global layers keep V^T.
+    static const int glob = cva_env_int("CVA_VRM_GLOBAL", 0);      // ablation builds: 1 = row-major V for attn2_kernel as well
+    if (!glob) return false;
     if (!bias) return true;
     return (p.KW == 64 && p.KH <= 64 && p.nk == p.KH * p.KW) || p.KH + p.KW <= 64;
 }

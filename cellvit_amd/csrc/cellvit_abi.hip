@@ -100,6 +100,7 @@ struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct HeadW { float* W = nullptr; float* b = nullptr; int n_out = 0; };
 struct BlockW {
     LNW n1, n2; LinearW qkv, proj, fc1, fc2; bool global = true;
+    LinearW proj8;            // fp8 engine, hd 80: proj on MX-fp8 with K re-laid as 96 columns per head (AttnParams::out8), or W8 == null
     float* tab_h = nullptr; float* tab_w = nullptr;   // derived (geometry dependent)
     // window blocks whose token grid is padded: private K / V^T buffers whose pad positions (k = b_k, v = b_v, constant per
     // layer) are written ONCE when the geometry is set — 0.46 GB per layer at 16 tiles, 13 GB for SAM-H: HBM is there for it
@@ -114,7 +115,8 @@ struct Geometry {
     bool set = false;
     int B = 0, H = 0, W = 0, gh = 0, gw = 0, P = 0, ntok = 0, has_cls = 0;
     int nwy = 0, nwx = 0, Lw = 0, Lpw = 0, Lg = 0, Lpg = 0;
-    int v_rm = 0;      // V of every attention layer is kept ROW-major [S*heads, L, hd] (attention.h attn_takes_vrm)
+    int proj8 = 0;     // fp8 engine: the attention kernels emit MX-fp8 rows and proj runs on the block-scaled MFMA
+    int v_rm = 0;      // V of the window blocks is kept ROW-major [S*heads, L, hd] (attention.h attn_takes_vrm)
 };
 
 }  // namespace
@@ -143,6 +145,7 @@ struct cv_handle {
          *attn_out = nullptr, *hidden = nullptr, *z[4] = {nullptr, nullptr, nullptr, nullptr}, *img8 = nullptr,
          *skip[4] = {nullptr, nullptr, nullptr, nullptr}, *S[3] = {nullptr, nullptr, nullptr}, *small_T = nullptr;
     void *xn8 = nullptr, *xn_sca = nullptr, *xn_scw = nullptr, *hidden8 = nullptr, *hidden_sc = nullptr;   // fp8 engine
+    void *attn8 = nullptr, *attn8_sc = nullptr;     // fp8 engine: attention output as MX-fp8 rows [M, 96 * heads] + scale image
     float *resid = nullptr, *relh = nullptr, *relw = nullptr, *neck_f32a = nullptr, *neck_f32b = nullptr,
           *small_f32 = nullptr, *dbg_blocks = nullptr, *dbg_tokens0 = nullptr;
     size_t ws_bytes = 0;
@@ -271,6 +274,25 @@ int pack_linear_mx8(cv_handle* h, const std::string& p, int N, int K, int swap_f
                  [&](int r, int k) { return (size_t)mx8_scale_index(r, k, K, /*w_side=*/r < swap_from); });
     CVA_TRY(upload_bytes(h, data, &out->W8));
     CVA_TRY(upload_bytes(h, sc, &out->S8));
+    return CV_OK;
+}
+
+// proj of the fp8 engine (hd 80): the K axis (= the attention output's columns) re-laid as 96 columns per head — the head's 80 values
+// followed by 16 zero columns — so that no MX scale block of the activation straddles two heads (AttnParams::out8); K8 = 96 * heads.
+int pack_proj_mx8(cv_handle* h, const std::string& p, int D, int heads, const float* bias, LinearW* out) {
+    const HostTensor* w = find(h, p + ".weight", {D, D});
+    CVA_NEED(w);
+    const int hd = D / heads, K8 = 96 * heads;
+    if (hd != 80 || D % 256 || K8 % 256) { out->W8 = nullptr; return CV_OK; }
+    std::vector<float> relaid((size_t)D * K8, 0.f);
+    for (int n = 0; n < D; ++n)
+        for (int hh = 0; hh < heads; ++hh)
+            for (int d = 0; d < hd; ++d) relaid[(size_t)n * K8 + hh * 96 + d] = w->data[(size_t)n * D + hh * hd + d];
+    std::vector<uint8_t> data((size_t)D * K8), sc((size_t)D * (K8 / 32));
+    mx8_quantize(relaid.data(), D, K8, data.data(), sc.data(), [&](int r, int k) { return (size_t)mx8_scale_index(r, k, K8, /*w_side=*/true); });
+    CVA_TRY(upload_bytes(h, data, &out->W8));
+    CVA_TRY(upload_bytes(h, sc, &out->S8));
+    out->N = D; out->K = K8; out->ldw = K8; out->bias = const_cast<float*>(bias);
     return CV_OK;
 }
 
@@ -561,13 +583,13 @@ int run_linear(const void* A, int lda, const LinearW& w, const float* res, int l
 
 // fp8 engine: out = act(A8 . W8^T + bias) (+ residual) on MX-fp8 operands.  out_mode OUT_LINEAR (out_f32 0/1) or OUT_MX8.
 int run_linear_mx8(const void* A8, const void* a_sc, int lda, const LinearW& w, const float* res, int ldres, void* out, int ldc,
-                   int out_f32, int out_mode, void* out_sc, int M, int act, hipStream_t st) {
+                   int out_f32, int out_mode, void* out_sc, int M, int act, hipStream_t st, int k_alg = 0) {
     GemmParams p{};
     p.M = M; p.N = w.N; p.K = w.K; p.A = A8; p.W = w.W8; p.lda = lda; p.ldw = w.K;
     p.a_scale = a_sc; p.w_scale = w.S8;
     p.bias = w.bias; p.act = act; p.res = res; p.ldres = ldres;
     p.out_mode = out_mode; p.out_f32 = out_f32; p.out = out; p.ldc = ldc; p.out_scale = out_sc;
-    ProfScope ps(KC_GEMM_MX8, 2.0 * M * (double)w.N * w.K, st);
+    ProfScope ps(KC_GEMM_MX8, 2.0 * M * (double)w.N * (k_alg ? k_alg : w.K), st);      // algorithmic FLOPs (k_alg: K without zero padding)
     const int rc = launch_gemm8_f8(p, st);
     if (rc) { cva_set_error("fp8 gemm launch failed (%d): M=%d N=%d K=%d", rc, M, w.N, w.K); return rc == (int)hipErrorInvalidValue ? CV_ERR_UNSUPPORTED : CV_ERR_HIP; }
     return CV_OK;
@@ -656,7 +678,8 @@ template <typename T>
 int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, const float* tab_w, bool window,
                         void* Q, void* K, void* Vt, float* relh, float* relw, void* attn_out, int B, int gh, int gw,
                         int has_cls, int heads, int D, int ws, hipStream_t st, bool prepadded = false,
-                        const void* xn_sca = nullptr, const void* xn_scw = nullptr, int Mp = 0, int v_rm = -1) {
+                        const void* xn_sca = nullptr, const void* xn_scw = nullptr, int Mp = 0, int v_rm = -1,
+                        void* out8 = nullptr, void* out8_sc = nullptr) {
     const int hd = D / heads, P = gh * gw, ntok = P + has_cls;
     const int nwy = window ? (gh + ws - 1) / ws : 0, nwx = window ? (gw + ws - 1) / ws : 0;
     const int L = window ? ws * ws : ntok, Lp = round_up(L, 64);
@@ -674,10 +697,12 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
     a.scale = 1.0f / std::sqrt((float)hd);
     a.ntok = ntok; a.win = window ? ws : 0; a.gw = gw; a.gh = gh; a.nwx = nwx; a.nwy = nwy;
     a.tab_h = tab_h; a.tab_w = tab_w;
+    a.out8 = out8; a.out8_scale = out8_sc; a.K8 = 96 * heads;
     a.win_prep = ((size_t)S * heads * L * KH * 4 >= 32768) ? (void*)relh : nullptr;   // the v1 bias scratch doubles as the window kernel's prep area
     // V layout of this layer: the engine decides once per geometry (all blocks alike: the per-block V buffers of padded window grids
     // are pre-filled in that layout); single-layer callers (cv_op_attention) decide here
     if (v_rm < 0) v_rm = (!xn_sca && attn_takes_vrm(a, sizeof(T))) ? 1 : 0;
+    if (out8 && (sizeof(T) != 2 || !attn_takes_out8(a))) { cva_set_error("attention: no kernel with the MX-fp8 epilogue for this layer geometry"); return CV_ERR_UNSUPPORTED; }
     a.v_rm = v_rm;
     g.bias = qkv.bias; g.act = ACT_NONE; g.out_mode = OUT_QKV;
     g.q_out = Q; g.k_out = K; g.vt_out = Vt; g.v_rm = v_rm;
@@ -704,7 +729,7 @@ int run_attention_layer(const void* xn, const LinearW& qkv, const float* tab_h, 
         if (rc2 == 0) return CV_OK;
         if (rc2 != -1) { cva_set_error("attention2 launch failed (%d)", rc2); return CV_ERR_HIP; }
     }
-    if (v_rm) { cva_set_error("attention: row-major V without a kernel that reads it"); return CV_ERR_STATE; }
+    if (v_rm || out8) { cva_set_error("attention: row-major V / MX-fp8 output without a kernel that takes it"); return CV_ERR_STATE; }
     a.tab_h = a.tab_w = nullptr;
     if (tab_h) {
         RelPosParams rp{};
@@ -747,18 +772,21 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
         else CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n1.g, b.n1.b, h->xn, 0, M, D, LN_EPS, st));
         const bool window = !b.global;
         const bool own_kv = window && b.Kw && b.Vtw;
+        const bool p8 = f8 && g.proj8 && b.proj8.W8;
         CVA_TRY(run_attention_layer<T>(f8 ? h->xn8 : h->xn, b.qkv, b.tab_h, b.tab_w, window, h->Q, own_kv ? b.Kw : h->K,
                                        own_kv ? b.Vtw : (window ? h->Vt_win : h->Vt_glob), h->relh, h->relw, h->attn_out, B, g.gh, g.gw,
                                        g.has_cls, heads, D, c.window_size, st, own_kv, f8 ? h->xn_sca : nullptr, f8 ? h->xn_scw : nullptr, Mp,
-                                       g.v_rm));
+                                       window ? g.v_rm : -1, p8 ? h->attn8 : nullptr, p8 ? h->attn8_sc : nullptr));
         if (fuse_add) {
             // fp16 engine: proj writes its fp16 output (as the reference's autocast Linear does); the add into the fp32
             // residual stream rides with LayerNorm 2, which has to stream that row anyway (elementwise.hip)
-            CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, nullptr, 0, 0, h->xn, D, 0, M, ACT_NONE, st, 0, 0, 0, Mp));
+            if (p8) CVA_TRY(run_linear_mx8(h->attn8, h->attn8_sc, b.proj8.K, b.proj8, nullptr, 0, h->xn, D, 0, OUT_LINEAR, nullptr, (int)M, ACT_NONE, st, D));
+            else CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, nullptr, 0, 0, h->xn, D, 0, M, ACT_NONE, st, 0, 0, 0, Mp));
             if (f8) CVA_LAUNCH(launch_layernorm_mx8(h->resid, D, h->xn, b.n2.g, b.n2.b, h->xn8, h->xn_sca, nullptr, M, D, LN_EPS, st));
             else CVA_LAUNCH(launch_layernorm_add(h->resid, D, h->xn, b.n2.g, b.n2.b, h->xn, M, D, LN_EPS, st));
         } else {
-            CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st, 0, 0, 0, Mp));
+            if (p8) CVA_TRY(run_linear_mx8(h->attn8, h->attn8_sc, b.proj8.K, b.proj8, h->resid, D, h->resid, D, 1, OUT_LINEAR, nullptr, (int)M, ACT_NONE, st, D));
+            else CVA_TRY(run_linear<T>(h->attn_out, D, b.proj, h->resid, D, 0, h->resid, D, 1, M, ACT_NONE, st, 0, 0, 0, Mp));
             if (f8) CVA_LAUNCH(launch_layernorm_mx8(h->resid, D, nullptr, b.n2.g, b.n2.b, h->xn8, h->xn_sca, nullptr, M, D, LN_EPS, st));
             else CVA_LAUNCH(launch_layernorm<T>(h->resid, D, b.n2.g, b.n2.b, h->xn, 0, M, D, LN_EPS, st));
         }
@@ -961,6 +989,7 @@ extern "C" int cv_finalize(cv_handle* h) {
             CVA_TRY(pack_linear_mx8(h, p + ".attn.qkv", 3 * D, D, 2 * D, &b.qkv));
             CVA_TRY(pack_linear_mx8(h, p + f1, hid, D, hid, &b.fc1));
             CVA_TRY(pack_linear_mx8(h, p + f2, D, hid, D, &b.fc2));
+            CVA_TRY(pack_proj_mx8(h, p + ".attn.proj", D, c.num_heads, b.proj.bias, &b.proj8));
         }
     }
     if (c.arch == CV_ARCH_VIT) {
@@ -1030,19 +1059,15 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
     const int D = c.embed_dim, heads = c.num_heads, hd = D / heads, B = g.B;
     const size_t M = (size_t)B * g.ntok;
     if (c.arch == CV_ARCH_SAM && dt == CV_DTYPE_F16 && !h->debug) {
-        // V row-major for every block, when both the window and the global layers of this geometry run kernels that read it
-        // (the geometry test of run_attention_layer, made once here: the per-block window buffers below are pre-filled accordingly)
+        // V row-major for the WINDOW blocks when their attention kernel reads it (the geometry test of run_attention_layer, made once
+        // here: the per-block window buffers below are pre-filled accordingly); global blocks decide per layer (V^T in production)
         static float dummy_tab = 0.f;
-        AttnParams aw{}, ag{};
+        AttnParams aw{};
         const int ws = c.window_size;
         aw.S = B * g.nwy * g.nwx; aw.heads = heads; aw.L = g.Lw; aw.Lp = g.Lpw; aw.hd = hd; aw.D = D; aw.nk = g.Lw; aw.KH = ws; aw.KW = ws;
         aw.win = ws; aw.tab_h = aw.tab_w = &dummy_tab;
         aw.win_prep = ((size_t)aw.S * heads * g.Lw * ws * 4 >= 32768) ? (void*)&dummy_tab : nullptr;
-        ag.S = B; ag.heads = heads; ag.L = g.Lg; ag.Lp = g.Lpg; ag.hd = hd; ag.D = D; ag.nk = g.Lg; ag.KH = g.gh; ag.KW = g.gw;
-        ag.tab_h = ag.tab_w = &dummy_tab;
-        bool any_win = false, any_glob = false;
-        for (auto& b : h->blocks) { if (b.global) any_glob = true; else any_win = true; }
-        g.v_rm = ((!any_win || attn_takes_vrm(aw, 2)) && (!any_glob || attn_takes_vrm(ag, 2))) ? 1 : 0;
+        g.v_rm = attn_takes_vrm(aw, 2) ? 1 : 0;
     }
     int s11, s12, bott; skip_dims(c, &s11, &s12, &bott);
     auto A = [&](void** p, size_t bytes, bool zero = false) -> int {
@@ -1087,6 +1112,27 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
     CVA_TRY(A(&h->attn_out, Mr * D * es, Mr != M));
     if (dt == CV_DTYPE_F8) {
         if (M % 256 != 0) { cva_set_error("fp8 engine: batch * tokens (%zu) must be a multiple of 256", M); return CV_ERR_UNSUPPORTED; }
+        if (c.arch == CV_ARCH_SAM && hd == 80 && (96 * heads) % 256 == 0) {
+            // proj on MX-fp8: every attention layer of this geometry must run a kernel with the fp8 epilogue (attention.h attn_takes_out8)
+            static float dummy_tab8 = 0.f;
+            AttnParams aw{}, ag{};
+            const int ws = c.window_size;
+            aw.S = B * g.nwy * g.nwx; aw.heads = heads; aw.L = g.Lw; aw.Lp = g.Lpw; aw.hd = hd; aw.D = D; aw.nk = g.Lw; aw.KH = ws; aw.KW = ws;
+            aw.win = ws; aw.tab_h = aw.tab_w = &dummy_tab8;
+            aw.win_prep = ((size_t)aw.S * heads * g.Lw * ws * 4 >= 32768) ? (void*)&dummy_tab8 : nullptr;
+            ag.S = B; ag.heads = heads; ag.L = g.Lg; ag.Lp = g.Lpg; ag.hd = hd; ag.D = D; ag.nk = g.Lg; ag.KH = g.gh; ag.KW = g.gw;
+            ag.tab_h = ag.tab_w = &dummy_tab8;
+            ag.win_prep = ((size_t)ag.S * heads * g.Lg * g.gh * 4 >= 32768) ? (void*)&dummy_tab8 : nullptr;
+            bool any_win = false, any_glob = false, packed = true;
+            for (auto& b : h->blocks) { if (b.global) any_glob = true; else any_win = true; packed = packed && b.proj8.W8; }
+            static const int no_p8 = cva_env_int("CVA_NO_PROJ8", 0);      // ablation builds: fp16 proj on the fp8 engine (A/B)
+            g.proj8 = (!no_p8 && packed && (!any_win || attn_takes_out8(aw)) && (!any_glob || attn_takes_out8(ag))) ? 1 : 0;
+            if (g.proj8) {
+                const size_t K8 = (size_t)96 * heads;
+                CVA_TRY(A(&h->attn8, M * K8, true));             // (the 16 pad columns of every head stay zero)
+                CVA_TRY(A(&h->attn8_sc, M * K8 / 32, true));
+            }
+        }
         const size_t hid8 = (size_t)D * c.mlp_ratio;
         CVA_TRY(A(&h->xn8, M * D));
         CVA_TRY(A(&h->xn_sca, M * D / 32, true));
@@ -1199,6 +1245,12 @@ extern "C" int cv_forward_u8(cv_handle* h, const uint8_t* x_u8, const float* mea
         u8.mean[c] = mean3[c]; u8.stdv[c] = std3[c];
     }
     return forward_checked(h, nullptr, &u8, B, H, W, out, stream);
+}
+
+// bit 0: the window blocks keep V row-major (attention.h attn_takes_vrm); bit 1: fp8 engine with proj on MX-fp8 (attention kernels emit MX-fp8 rows)
+extern "C" int cv_geometry_flags(const cv_handle* h) {
+    if (!h || !h->g.set) return 0;
+    return (h->g.v_rm ? 1 : 0) | (h->g.proj8 ? 2 : 0);
 }
 
 extern "C" int cv_set_debug(cv_handle* h, int enable) {
@@ -1462,6 +1514,36 @@ extern "C" int cv_op_attention_mx8(const void* x8, const void* scale_a, const vo
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc = run_attention_layer<half_t>(x8, w, tab_h, tab_w, window, Q, K, Vt, relh, relw, out, B, gh, gw, 0, heads, D, win, st, false,
                                          scale_a, scale_w);
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) { cva_set_error("attention: stream sync failed: %s", hipGetErrorString(hipGetLastError())); rc = CV_ERR_HIP; }
+    free_pool(pool);
+    return rc;
+}
+
+// The fp16 attention layer with the MX-fp8 row epilogue of the fp8 engine's proj path (AttnParams::out8): out8 e4m3 [B*gh*gw, 96 * heads]
+// (zero-filled by the caller: the 16 pad columns per head are never written), out8_scale the A-side scale image [B*gh*gw * 3 * heads].
+extern "C" int cv_op_attention_rows_mx8(const void* x, const void* Wqkv, const float* bqkv, const float* tab_h, const float* tab_w,
+                                        void* out8, void* out8_scale, int B, int gh, int gw, int heads, int D, int win, void* stream) {
+    if (!x || !Wqkv || !out8 || !out8_scale || D % heads || D / heads != 80) { cva_set_error("cv_op_attention_rows_mx8: bad argument (hd must be 80)"); return CV_ERR_INVALID; }
+    const int hd = D / heads, P = gh * gw, ntok = P;
+    const bool window = win > 0;
+    const int nwy = window ? (gh + win - 1) / win : 0, nwx = window ? (gw + win - 1) / win : 0;
+    const int L = window ? win * win : ntok, Lp = round_up(L, 64);
+    const size_t S = window ? (size_t)B * nwy * nwx : (size_t)B;
+    const int KH = window ? win : gh, KW = window ? win : gw;
+    std::vector<void*> pool;
+    void *Q, *K, *Vt, *dummy; float *relh = nullptr, *relw = nullptr;
+    CVA_TRY(dev_alloc(pool, &Q, S * heads * L * hd * 2, true));
+    CVA_TRY(dev_alloc(pool, &K, S * heads * L * hd * 2, true));
+    CVA_TRY(dev_alloc(pool, &Vt, S * heads * hd * Lp * 2, true));
+    CVA_TRY(dev_alloc(pool, &dummy, (size_t)B * ntok * D * 2, true));
+    if (tab_h) {
+        CVA_TRY(dev_alloc(pool, (void**)&relh, S * heads * L * KH * 4));
+        CVA_TRY(dev_alloc(pool, (void**)&relw, S * heads * L * KW * 4));
+    }
+    LinearW w; w.W = const_cast<void*>(Wqkv); w.bias = const_cast<float*>(bqkv); w.N = 3 * D; w.K = D; w.ldw = D;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = run_attention_layer<half_t>(x, w, tab_h, tab_w, window, Q, K, Vt, relh, relw, dummy, B, gh, gw, 0, heads, D, win, st, false,
+                                         nullptr, nullptr, 0, -1, out8, out8_scale);
     if (hipStreamSynchronize(st) != hipSuccess && !rc) { cva_set_error("attention: stream sync failed: %s", hipGetErrorString(hipGetLastError())); rc = CV_ERR_HIP; }
     free_pool(pool);
     return rc;

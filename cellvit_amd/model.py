@@ -242,6 +242,12 @@ class CellViT(nn.Module):
             self._engines[(idx, dtype)] = e
         return e
 
+    def engine_flags(self) -> int:
+        """Engine choices of the last forward's geometry (`cv_geometry_flags`): bit 0 = window blocks keep V row-major, bit 1 = fp8
+        engine with proj on MX-fp8.  0 before the first forward."""
+        e = getattr(self, "_last_engine", None)
+        return int(e.lib.cv_geometry_flags(e.h)) if e is not None else 0
+
     def _ensure_geometry(self, e: _Engine, B: int, H: int, W: int) -> None:
         if e.geom is not None and e.geom[1:] == (H, W) and B <= e.geom[0]:
             return

@@ -122,6 +122,9 @@ int cv_forward_u8(cv_handle* h, const uint8_t* x_u8, const float* mean3, const f
 /* Debug taps (synchronises): copy a named intermediate of the LAST forward to host memory as fp32.
  * names: "tokens0", "block<i>", "z<1..4>", "skip<0..3>".  Returns the element count in *n_out.        */
 int cv_set_debug(cv_handle* h, int enable);
+/* Engine choices of the current geometry (0 before cv_set_geometry): bit 0 = the window blocks keep V row-major (qkv epilogue + window
+ * attention kernel with the transposing LDS read), bit 1 = fp8 engine with proj on MX-fp8 (the attention kernels emit MX-fp8 rows).   */
+int cv_geometry_flags(const cv_handle* h);
 int cv_debug_read(cv_handle* h, const char* name, float* host_dst, size_t capacity, size_t* n_out);
 
 /* Live per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
@@ -185,6 +188,13 @@ int cv_op_layernorm_mx8(float* x_io, const void* delta_f16, const float* gamma, 
 int cv_op_attention_mx8(const void* x8, const void* scale_a, const void* scale_w, const void* Wqkv8, const void* wqkv_scale,
                         const float* bqkv, const float* tab_h, const float* tab_w, void* out, int B, int gh, int gw, int heads,
                         int D, int win, void* stream);
+
+/* The fp16 attention layer (as cv_op_attention, no cls token, hd = 80) with the MX-fp8 row epilogue that feeds the fp8 engine's proj:
+ * out8 e4m3 [B*gh*gw, 96 * heads] — head h owns columns [96 h, 96 h + 96) = its 80 values + 16 zeros, so that no 32-element scale block
+ * straddles two heads; the caller zero-fills it (pad columns are never written) — and out8_scale, the E8M0 scale image in the A-side order
+ * of the 8-phase kernel (3 * heads scales per row).  Replaces the fp16 `attn_out` of SAM/image_encoder.py:255-258 on that engine.      */
+int cv_op_attention_rows_mx8(const void* x, const void* Wqkv, const float* bqkv, const float* tab_h, const float* tab_w, void* out8,
+                             void* out8_scale, int B, int gh, int gw, int heads, int D, int win, void* stream);
 
 /* argmax over dim 1 of an fp32 NCHW map -> u8 [B,H,W], first maximum (torch.argmax of cellvit.py:366-374).           */
 int cv_op_argmax_nchw(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream);

@@ -197,6 +197,66 @@ def test_attention_layer_mx8_vs_fp16(win):
     assert d < 2e-2, d
 
 
+@pytest.mark.parametrize("B,win", [(1, 0), (1, 14), (2, 14)])
+def test_attention_rows_mx8_for_the_proj(B, win):
+    """The attention kernels' MX-fp8 epilogue (fp8 engine: proj on the block-scaled MFMA): head h owns columns [96 h, 96 h + 96) of the row —
+    80 values + 16 zeros — with one E8M0 scale per 32 columns in the A-side image.  Against the fp16 layer on the same inputs: scales ==
+    the OCP shared exponent of the fp16 values (up to fp16-rounding at exponent boundaries), elements within e4m3 rounding, pads zero;
+    then the proj contraction on those rows == the fp64 product of the dequantised operands (K = 1536 with the re-laid weight)."""
+    gh = gw = 16
+    heads, D = 16, 1280
+    hd, K8 = D // heads, 96 * heads
+    M = B * gh * gw
+    rng = np.random.default_rng(7 + win + B)
+    X = (rng.standard_normal((M, D)) * 0.5).astype(np.float32)
+    Wq = (rng.standard_normal((3 * D, D)) / np.sqrt(D)).astype(np.float32)
+    bq = (0.1 * rng.standard_normal(3 * D)).astype(np.float32)
+    side = win if win else gh
+    th = (0.05 * rng.standard_normal((2 * side - 1, hd))).astype(np.float32)
+    tw = (0.05 * rng.standard_normal((2 * side - 1, hd))).astype(np.float32)
+    lib = _lib.load()
+    tx, twq, tbq, tth, ttw = _dev(X).half(), _dev(Wq).half(), _dev(bq), _dev(th), _dev(tw)
+    out16 = torch.empty((M, D), device=DEV, dtype=torch.float16)
+    _lib.check(lib.cv_op_attention(_lib.DTYPE_F16, _p(tx), _p(twq), _p(tbq), _p(tth), _p(ttw), _p(out16), B, gh, gw, 0, heads, D, win, _stream()))
+    o8 = torch.zeros((M, K8), device=DEV, dtype=torch.uint8)
+    osc = torch.zeros((M * K8 // 32,), device=DEV, dtype=torch.uint8)
+    _lib.check(lib.cv_op_attention_rows_mx8(_p(tx), _p(twq), _p(tbq), _p(tth), _p(ttw), _p(o8), _p(osc), B, gh, gw, heads, D, win, _stream()))
+    torch.cuda.synchronize()
+    ref = out16.float().cpu().numpy().reshape(M, heads, hd)
+    d8 = o8.cpu().numpy().reshape(M, heads, 96)
+    assert not d8[:, :, 80:].any(), "pad columns must stay zero"
+    sc = mx8.untile_scales(osc.cpu().numpy(), M, K8, False).reshape(M, heads, 3)
+    deq = mx8.dequantize(d8.reshape(M, K8), sc.reshape(M, K8 // 32)).reshape(M, heads, 96)[:, :, :80]
+    refp = np.concatenate([ref, np.zeros((M, heads, 16), np.float32)], 2).reshape(M, heads, 3, 32)
+    blk = np.abs(refp).max(-1)                                            # block maxima of the fp16 output
+    want_sb = np.maximum(((blk.astype(np.float32).view(np.uint32) >> 23) & 0xff).astype(np.int64) - 8, 0)
+    agree = float((sc == want_sb).mean())
+    assert agree > 0.99, agree            # the kernel quantises its fp32 accumulators, the check uses the fp16-rounded output: rare exponent flips
+    err = np.abs(deq - ref)
+    bound = np.maximum(np.abs(ref) * 2.0 ** -3, np.repeat(blk, 32, -1).reshape(M, heads, 96)[:, :, :80] * 2.0 ** -6) + 2e-3
+    assert (err <= bound).all(), float((err - bound).max())
+    print(f"\n[attention rows mx8 B={B} win={win}] scale agreement {agree:.4f}, max abs err {err.max():.3e} (abs max {np.abs(ref).max():.3f})")
+    # proj on those rows: re-laid weight (zero columns for the pads), exact on the quantised operands
+    Wp = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+    Wr = np.zeros((D, heads, 96), np.float32)
+    Wr[:, :, :80] = Wp.reshape(D, heads, hd)
+    w8, ws_rm = mx8.quantize(Wr.reshape(D, K8), mx8.ROW_MAJOR)
+    _, ws_w = mx8.quantize(Wr.reshape(D, K8), mx8.W_SIDE)
+    out = torch.empty((M, D), device=DEV, dtype=torch.float32)
+    _lib.check(lib.cv_op_linear_mx8(_p(o8), _p(osc), None, _p(_dev(w8)), _p(_dev(ws_w)), None, None, _p(out), 1, None, M, D, K8, 0, _stream()))
+    torch.cuda.synchronize()
+    A = mx8.dequantize(d8.reshape(M, K8), sc.reshape(M, K8 // 32))
+    Wd = mx8.dequantize(w8, ws_rm.reshape(D, K8 // 32))
+    want = A @ Wd.T
+    mag = np.abs(A) @ np.abs(Wd).T
+    assert (np.abs(out.double().cpu().numpy() - want) <= 4e-5 * mag + 1e-6).all()
+    # and it approximates the fp16 proj of the fp16 rows
+    full = ref.reshape(M, D).astype(np.float64) @ Wp.astype(np.float64).T
+    rel = np.abs(want - full).max() / np.abs(full).max()
+    print(f"[proj mx8 on those rows] max err relative to the output's abs max: {rel:.3e}")
+    assert rel < 0.1, rel                 # e4m3 operands (3 mantissa bits) on both sides of a K = 1280 contraction: measured 5-6 %
+
+
 def test_fp8_engine_is_refused_where_it_does_not_apply():
     from cellvit_amd.model import CellViT256
     from cellvit_amd.spec import cellvit256_config
@@ -209,15 +269,20 @@ def test_fp8_engine_is_refused_where_it_does_not_apply():
 
 @pytest.mark.parametrize("name", ["samh_256", "samh_1024"])
 def test_forward_fp8_error_statistics(name):
-    """configs[4]: SAM-H, MX-fp8 qkv / fc1 / fc2, against the goldens of the imported (fp32) reference.  Stated tolerance
-    (what three fp8 contractions per block over 32 blocks hold): logits max-abs < 0.25, mean-abs < 0.03, argmax agreement
-    >= 0.97 / 0.95 — and for reference the same statistics of the fp16 engine are printed next to them."""
+    """configs[4]: SAM-H, MX-fp8 qkv / proj / fc1 / fc2, against the goldens of the imported (fp32) reference.  Stated tolerance
+    (what FOUR fp8 contractions per block over 32 blocks hold — round 4 added proj, fed by MX-fp8 attention rows): logits max-abs
+    < 0.25, mean-abs < 0.035, argmax agreement >= 0.96 / 0.945 (measured 0.17-0.21 / 0.025-0.029 / 0.969-0.970 / 0.956-0.957; with
+    the fp16 proj of round 3: 0.15 / 0.024 / 0.975 / 0.960) — and for reference the same statistics of the fp16 engine are printed next
+    to them.  Random-weight logits have no margins, so every extra rounding moves the argmax of ~0.5 % of the pixels; what the engine
+    does to INSTANCES is the gate below (PQ 0.9997)."""
     cfg, sd, x, gold = load_case(name)
     stats = {}
     for dt in ("fp16", "fp8"):
         m = _model(cfg, sd, dt)
         out = m(x.cuda(), retrieve_tokens=True)
         torch.cuda.synchronize()
+        if dt == "fp8":       # SAM-H (hd 80): proj runs on MX-fp8 as well, fed by the attention kernels' MX-fp8 rows
+            assert m.engine_flags() & 2, m.engine_flags()
         st = {}
         for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
             a = out[k].float().cpu().numpy()
@@ -237,8 +302,8 @@ def test_forward_fp8_error_statistics(name):
     print(f"\n[{name}] (max abs, mean abs) / argmax agreement vs the imported reference:\n   fp16 {stats['fp16']}\n   fp8  {stats['fp8']}")
     s8 = stats["fp8"]
     for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
-        assert s8[k][0] < 0.25 and s8[k][1] < 0.03, (k, s8[k])
-    assert s8["nuclei_binary_map_argmax"] >= 0.97 and s8["nuclei_type_map_argmax"] >= 0.95, s8
+        assert s8[k][0] < 0.25 and s8[k][1] < 0.035, (k, s8[k])
+    assert s8["nuclei_binary_map_argmax"] >= 0.96 and s8["nuclei_type_map_argmax"] >= 0.945, s8
 
 
 def test_samh_1024_fp8_instance_level_gate():
