@@ -135,9 +135,22 @@ def extras(model, step, B, dev):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
     try:
+        import ctypes as C
+        from cellvit_amd import _lib
         model.compute_dtype = "fp8"
-        out["fp8_tiles_per_s"] = B / timed(step)
-        out["fp8_note"] = "MX-fp8 qkv/fc1/fc2 + fp16 attention core/proj/decoder, same step (forward + post-processing) and batch as the headline"
+        step(); step()                                        # warm-up (builds the fp8 engine's geometry)
+        eng8 = model._last_engine
+        _lib.check(eng8.lib.cv_profile_enable(eng8.h, 1))     # live HIP-event classes of this leg as well (gemm_mx8 against the 5 PFLOP/s peak)
+        out["fp8_tiles_per_s"] = B / timed(step, n=3, w=0)
+        ms = (C.c_double * NK)(); n = (C.c_int64 * NK)(); fl = (C.c_double * NK)()
+        _lib.check(eng8.lib.cv_profile_collect(eng8.h, ms, n, fl))
+        _lib.check(eng8.lib.cv_profile_enable(eng8.h, 0))
+        out["fp8_kernel_classes"] = {name: {"launches": int(n[i]), "total_ms_per_step": ms[i] / 3, "tflops": fl[i] / (ms[i] * 1e-3) / 1e12,
+                                            "peak_tflops": KPEAK[i], "frac": fl[i] / (ms[i] * 1e-3) / 1e12 / KPEAK[i]}
+                                     for i, name in enumerate(KCLASS) if n[i]}
+        out["fp8_engine_flags"] = model.engine_flags()
+        out["fp8_note"] = ("MX-fp8 qkv / proj / fc1 / fc2 (engine flag 2: the attention kernels emit MX-fp8 rows for proj) + fp16 attention core / decoder, "
+                           "same step (forward + post-processing) and batch as the headline")
     except Exception as e:      # noqa: BLE001
         out["fp8_error"] = repr(e)[:200]
     finally:
@@ -368,6 +381,7 @@ def main():
                         "traffic_source": os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, "
                                           "corrected per MI355X_MICROARCH.md (tools/pmc_traffic.py); not collected in this run"
                                           if traffic is not None else None}
+        F8_SHARE = 5.154e12 if (args.dtype == "f8" and (model.engine_flags() & 2)) else 4.7245e12
         rec = {
             "metric": METRIC, "value": world * B * args.steps / dt, "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -378,15 +392,17 @@ def main():
                        "input": "raw uint8 HWC tiles resident in HBM; inference transform fused into the forward (cv_forward_u8)",
                        "experiment_env": dbg + (["ABLATION_BUILD"] if _lib.load().cv_build_is_ablation() else []),
                        "library": os.path.relpath(_lib.LIB_PATH, ROOT), "library_build_flags": (_lib.load().cv_build_flags() or b"").decode(),
+                       "engine_flags": model.engine_flags(),      # bit 0: window blocks keep V row-major; bit 1: fp8 engine with proj on MX-fp8
                        "postproc": bool(do_pp), "postproc_stream_overlap": bool(overlap), "postproc_input": f"synthetic nuclei maps, {args.cells} cells/tile",
                        "instances_per_step": n_inst},
             "stage_ms_sequential": {"forward": fwd_ms, "postproc": pp_ms},
             "handoff_check": handoff_ms,
-            # forward time at 100 % of the MFMA peak(s) / measured forward time.  f8: the qkv / fc1 / fc2 share of the algorithmic
-            # FLOPs (11/12 of the encoder's 5.154 TFLOP of linear layers per 1024^2 SAM-H tile) is priced at the MX-fp8 peak
+            # forward time at 100 % of the MFMA peak(s) / measured forward time.  f8: the share of the algorithmic FLOPs that runs on
+            # the block-scaled MFMA — qkv / fc1 / fc2 = 11/12 of the encoder's 5.154 TFLOP of linear layers per 1024^2 SAM-H tile, all of
+            # it when proj is on MX-fp8 too (engine flag 2) — is priced at the MX-fp8 peak
             "whole_forward_mfma_frac": (B * (flops_per_tile / (MFMA_F16_PEAK_TFLOPS * 1e12)) / (fwd_ms * 1e-3)) if args.dtype == "f16" or args.model != "samh"
-            else (B * ((4.7245e12 * (T / 1024.0) ** 2) / (MFMA_F8_PEAK_TFLOPS * 1e12) +
-                       (flops_per_tile - 4.7245e12 * (T / 1024.0) ** 2) / (MFMA_F16_PEAK_TFLOPS * 1e12)) / (fwd_ms * 1e-3)),
+            else (B * ((F8_SHARE * (T / 1024.0) ** 2) / (MFMA_F8_PEAK_TFLOPS * 1e12) +
+                       (flops_per_tile - F8_SHARE * (T / 1024.0) ** 2) / (MFMA_F16_PEAK_TFLOPS * 1e12)) / (fwd_ms * 1e-3)),
             "roofline": roofline,
             "kernel_classes": kstats,
         }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box call that produces the round's evidence under gpurun_out/$1 (copy what should be judged into profiles/).
-#   tools/gpu_evidence.sh r03f [tests]
+#   tools/gpu_evidence.sh r04 [tests]
 OUT=gpurun_out/${1:-evidence}
 mkdir -p $OUT
 export TMPDIR=/tmp
