@@ -12,7 +12,8 @@
 // bank-conflict fix is the source-side XOR  piece ^= ((row >> 2) & 1) << 1  (conflict-free for ANY base pixel,
 // which matters because the nine taps read the halo at nine different alignments).
 // 512 threads = 8 waves; wave w owns image rows 2w, 2w+1 of the 16 x 32 pixel tile (64 pixels) x 64 output
-// channels = 4 x 4 fragments of v_mfma_f32_16x16x32_f16.  Epilogue: LDS transpose -> 16-byte NHWC stores.
+// channels = 4 x 4 fragments of v_mfma_f32_16x16x32_f16.  Epilogue: LDS transpose -> 16-byte NHWC stores (8-wave kernel);
+// the 4-wave kernel of the 512^2 / 1024^2 layers stores straight from the accumulators (cout_of_row).
 #include <stdlib.h>
 
 #include "common.h"
@@ -291,6 +292,16 @@ __global__ __launch_bounds__(NTH, MINW) void conv3x3_halo_kernel(const GemmParam
 // (76.8 KB), a wave owns 4 image rows = 128 pixels x 64 output channels (8 x 4 fragments, 128 accumulator VGPRs, 12 fragment
 // reads per 32 MFMAs instead of 8 per 16), and two workgroups share a CU: they run unsynchronised, so one's DMA waits,
 // prologue and epilogue overlap the other's MFMAs — ping-pong at workgroup granularity, no extra barriers.
+// Direct epilogue.  The MFMAs run with the operands exchanged (C^T = W . X^T: lane (g, li) of fragment (i, j) holds pixel li of slab i and
+// the fragment's filter rows 4g .. 4g+3), and the 64 filter rows of the block are permuted when they are staged: LDS row j*16 + 4g + r
+// carries output channel (j >> 1)*32 + g*8 + (j & 1)*4 + r.  A lane then owns, per pixel, channels [g*8, g*8+8) and [32 + g*8, 32 + g*8+8):
+// two 16-byte NHWC stores per slab with the four lanes of a pixel covering 64 contiguous bytes each — and exactly the two B operands
+// (pixel li, K chunk g) of the fused 1x1 head's MFMAs.  No LDS round trip: the former epilogue wrote every slab to LDS with 16
+// ds_write_b16 per lane and read it back transposed; for the 64-channel layers at 1024^2 the kernel's non-MFMA skeleton was 482 of 775 us
+// (profiles/r02_exp_conv_halo4_ablation.txt) — measured gain 2 - 4 % per layer (profiles/r04_p_conv_direct_epilogue_ab.txt): most of that
+// skeleton is the layers' HBM traffic, not the epilogue's instructions.
+__device__ __forceinline__ int cout_of_row(int n) { return ((n >> 5) << 5) + (((n >> 2) & 3) << 3) + (((n >> 4) & 1) << 2) + (n & 3); }
+
 constexpr int NTH4 = 256, NWAVE4 = 4;
 constexpr int MAX_H4 = (HALO_INSTR + NWAVE4 - 1) / NWAVE4;   // 10
 constexpr int MAX_W4 = (W_INSTR + NWAVE4 - 1) / NWAVE4;      // 9
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
         if (!(ABL & 4))                                                                                          \
         _Pragma("unroll") for (int i = (I0); i < (I0) + 4; ++i)                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[i], Bf[S][j], acc[i][j], 0, 0, 0);         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf[S][j], Af[i], acc[i][j], 0, 0, 0);         \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
     } while (0)
 // in flight on entry: LO(TAP) [8 reads].  LAST: no prefetch of the next tap (the stage is about to be overwritten).
@@ -414,7 +425,8 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
             const int k = wave + NWAVE4 * i;
             if (k < W_INSTR && !((ABL & 1) && ch > 0)) {
                 const int tap = k >> 2, n = (k & 3) * 16 + (lane >> 2);
-                const half_t* s = (n0 + n) < p.N ? Wp + (long)(n0 + n) * p.ldw + tap * ctot + ((lane & 3) ^ swz(n)) * 8 + c0 : Zp;
+                const int nc = cout_of_row(n);                                  // LDS row n holds the taps of output channel n0 + nc
+                const half_t* s = (n0 + nc) < p.N ? Wp + (long)(n0 + nc) * p.ldw + tap * ctot + ((lane & 3) ^ swz(n)) * 8 + c0 : Zp;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
                                                  (__attribute__((address_space(3))) void*)(sW + k * 1024), 16, 0, 0);
             }
@@ -435,10 +447,8 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
         __syncthreads();                                  // every wave has finished reading the stage
     }
 
-    // ---- epilogue: as above, eight 16-pixel slabs per wave ----
-    float* st = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+    // ---- epilogue: direct (see cout_of_row), eight 16-pixel slabs per wave ----
     const bool fuse = p.head_W != nullptr;
-    float* hw = reinterpret_cast<float*>(smem + 36864);
     // Fused 1x1 head (64 -> head_nout <= 8 channels, + argmax): two MFMAs per 16-pixel slab on the fp16 activations —
     // C^T[out n][pixel] = W[n][:] . act[pixel][:], lane (g, li) then owns pixel li and outputs g*4 .. g*4+3 — instead of
     // 16 * nout fp32 FMAs per lane and slab (the six-output type head cost 3.5 ms more per step than the two-output heads).
@@ -446,110 +456,76 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
     half8_t wf[2]; f32x4 hb4 = (f32x4)(0.f);
     wf[0] = (half8_t)(0); wf[1] = (half8_t)(0);
     if (fuse) {
-        for (int i = tid; i < p.head_nout * 65; i += NTH4)
-            hw[i] = i < p.head_nout * 64 ? p.head_W[i] : p.head_b[i - p.head_nout * 64];
-        __syncthreads();
         if (li < p.head_nout) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) wf[ks][e] = (half_t)hw[li * 64 + ks * 32 + g * 8 + e];
+                for (int e = 0; e < 8; ++e) wf[ks][e] = (half_t)p.head_W[li * 64 + ks * 32 + g * 8 + e];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (g * 4 + r < p.head_nout) hb4[r] = hw[p.head_nout * 64 + g * 4 + r];
+        for (int r = 0; r < 4; ++r) if (g * 4 + r < p.head_nout) hb4[r] = p.head_b[g * 4 + r];
     }
-    float bv[4];
+    float bv[16];                                   // bias of the lane's channels: fragment j -> n0 + (j >> 1)*32 + g*8 + (j & 1)*4 + r
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int n = n0 + j * 16 + li; bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f; }
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + (j >> 1) * 32 + g * 8 + (j & 1) * 4 + r;
+            bv[j * 4 + r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        }
+    const bool relu = p.act == ACT_RELU;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int y = y0 + 4 * wave + (i >> 1);
-        const int xb = x0 + (i & 1) * 16;
-        if (fuse) {
-            half_t* sh = reinterpret_cast<half_t*>(st);          // [16 pixels][72]: 144-byte pitch, conflict-free 16-byte fragment reads
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bv[j];
-                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    sh[(g * 4 + r) * 72 + j * 16 + li] = (half_t)v;
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const half8_t p0 = *reinterpret_cast<const half8_t*>(sh + li * 72 + g * 8);
-            const half8_t p1 = *reinterpret_cast<const half8_t*>(sh + li * 72 + 32 + g * 8);
-            f32x4 ha = hb4;
-            ha = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], p0, ha, 0, 0, 0);
-            ha = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], p1, ha, 0, 0, 0);
-            const int x = xb + li;
-            const bool valid = y < H && x < W;
-            const long hwp = (long)H * W, pix = (long)y * W + x;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (valid && g * 4 + r < p.head_nout) p.head_logits[((long)b * p.head_nout + g * 4 + r) * hwp + pix] = ha[r];
-            // first maximum over outputs 0 .. head_narg-1 (strict >, ascending n): local over r, then lanes g = 0 | 1
-            float bvv = ha[0]; int best = g * 4;
-            if (g != 0 && !(g * 4 < p.head_narg)) bvv = -INFINITY;
-#pragma unroll
-            for (int r = 1; r < 4; ++r)
-                if (g * 4 + r < p.head_narg && ha[r] > bvv) { bvv = ha[r]; best = g * 4 + r; }
-            const float ov = __shfl_xor(bvv, 16);
-            const int oi = __shfl_xor(best, 16);
-            if (p.head_narg > 4 && ov > bvv) best = oi;
-            if (g == 0 && valid && p.head_argmax) p.head_argmax[(long)b * hwp + pix] = (uint8_t)best;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            continue;
-        }
-        if (!p.out_f32) {                                        // fp16 output: the slab goes through LDS already rounded
-            half_t* sh = reinterpret_cast<half_t*>(st);          // [16 pixels][72]
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bv[j];
-                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    sh[(g * 4 + r) * 72 + j * 16 + li] = (half_t)v;
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (y < H) {
-                half_t* out = reinterpret_cast<half_t*>(p.out);
-#pragma unroll
-                for (int rr = lane >> 3; rr < 16; rr += 8) {
-                    const int x = xb + rr, n = n0 + (lane & 7) * 8;
-                    if (x < W && n < p.N)
-                        *reinterpret_cast<half8_t*>(out + (((long)b * H + y) * W + x) * p.ldc + n) =
-                            *reinterpret_cast<const half8_t*>(sh + rr * 72 + (lane & 7) * 8);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            continue;
-        }
+        const int x = x0 + (i & 1) * 16 + li;
+        const bool valid = y < H && x < W;
+        float v[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r] + bv[j];
-                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                st[(g * 4 + r) * 68 + j * 16 + li] = v;
+                const float t = acc[i][j][r] + bv[j * 4 + r];
+                v[j * 4 + r] = relu ? fmaxf(t, 0.f) : t;
             }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (y < H) {
-            float* out = reinterpret_cast<float*>(p.out);
-            for (int rr = lane >> 4; rr < 16; rr += 4) {
-                const int x = xb + rr, n = n0 + (lane & 15) * 4;
-                if (x < W && n < p.N) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * 68 + (lane & 15) * 4);
-                    *reinterpret_cast<f32x4*>(out + (((long)b * H + y) * W + x) * p.ldc + n) = v;
+        if (p.out_f32 && !fuse) {
+            float* o = reinterpret_cast<float*>(p.out) + (((long)b * H + y) * W + x) * p.ldc + n0 + g * 8;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (valid && n0 + q * 32 + g * 8 < p.N) {
+                    *reinterpret_cast<f32x4*>(o + q * 32) = (f32x4){v[q * 8 + 0], v[q * 8 + 1], v[q * 8 + 2], v[q * 8 + 3]};
+                    *reinterpret_cast<f32x4*>(o + q * 32 + 4) = (f32x4){v[q * 8 + 4], v[q * 8 + 5], v[q * 8 + 6], v[q * 8 + 7]};
                 }
-            }
+            continue;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        half8_t hq[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hq[q][e] = (half_t)v[q * 8 + e];
+        if (!fuse) {
+            half_t* o = reinterpret_cast<half_t*>(p.out) + (((long)b * H + y) * W + x) * p.ldc + n0 + g * 8;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (valid && n0 + q * 32 + g * 8 < p.N) *reinterpret_cast<half8_t*>(o + q * 32) = hq[q];
+            continue;
+        }
+        f32x4 ha = hb4;
+        ha = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], hq[0], ha, 0, 0, 0);
+        ha = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], hq[1], ha, 0, 0, 0);
+        const long hwp = (long)H * W, pix = (long)y * W + x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (valid && g * 4 + r < p.head_nout) p.head_logits[((long)b * p.head_nout + g * 4 + r) * hwp + pix] = ha[r];
+        // first maximum over outputs 0 .. head_narg-1 (strict >, ascending n): local over r, then lanes g = 0 | 1
+        float bvv = ha[0]; int best = g * 4;
+        if (g != 0 && !(g * 4 < p.head_narg)) bvv = -INFINITY;
+#pragma unroll
+        for (int r = 1; r < 4; ++r)
+            if (g * 4 + r < p.head_narg && ha[r] > bvv) { bvv = ha[r]; best = g * 4 + r; }
+        const float ov = __shfl_xor(bvv, 16);
+        const int oi = __shfl_xor(best, 16);
+        if (p.head_narg > 4 && ov > bvv) best = oi;
+        if (g == 0 && valid && p.head_argmax) p.head_argmax[(long)b * hwp + pix] = (uint8_t)best;
     }
 }
 

@@ -83,6 +83,24 @@ using namespace g8;
     } while (0)
 
 #define G8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// The lane id recomputed from the execution mask (two instructions, NO live register) and opaque to the optimiser: everything a tile boundary
+// derives from the lane (DMA row offsets, bias offsets, epilogue addresses) is loop invariant, so the compiler hoists it out of the persistent
+// tile loop, keeps it live across the K loop — which needs all 256 VGPRs — and spills it; every reload at a tile boundary is a scratch load +
+// s_waitcnt vmcnt(0), i.e. a full round trip behind the next tile's prologue DMA or the epilogue's stores.  With this (and the opaque divisors
+// of gemm8_epi.h) every instantiation has ScratchSize 0: epilogue 6.6 -> 6.2 us per tile, fc1 -1.6 %, qkv -1.0 % (profiles/r04_m_gemm_timeline.txt,
+// r04_no_gemm8_spills_lean_epilogue_ab.txt).
+__device__ __forceinline__ int g8_fresh_lane() {
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
+#ifdef CVA_ABLATION      // experiment: per-tile timeline of wave 0 / wave 4 of the first 8 workgroups (CVA_GEMM_DBG & 32768), written to p.park
+#define G8_STAMP(slot)                                                                                                  \
+    do { if ((p.dbg & 32768) && p.park && blockIdx.x < 8 && (wave & 3) == 0 && lane == 0 && item < 24)                  \
+             reinterpret_cast<long long*>(p.park)[((blockIdx.x * 2 + (wave >> 2)) * 24 + item) * 8 + (slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define G8_STAMP(slot) do { } while (0)
+#endif
 
 // 16 MFMAs of quadrant (MH, NH): C[MH*4+mi][NH*2+nj] += A[mi][ks] * W[nj][ks]
 #define G8_MMQ(n, a, b, MH, NH)                                                                             \
@@ -184,10 +202,12 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     constexpr bool PSHIFT = OMODE == OUT_LINEAR && TRANS == 1 && !F8 && !CV3 && ABL == 0;
     const int ntl = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     int phi = 0;
-    if (PSHIFT && p.park && ntl >= 2) phi = ((((int)blockIdx.x & 7) * nk) >> 3) & ~1;
+    if (PSHIFT && p.park && ntl >= 2 && !(p.dbg & 32768)) phi = ((((int)blockIdx.x & 7) * nk) >> 3) & ~1;
     const int nitems = ntl + (phi ? 1 : 0);
     int kcnt_next = nk;                 // K tiles of the item whose DMA is issued next (even, >= 2)
     auto tile_setup = [&](int item, int& m0, int& n0, bool& swap) {
+        const int fl = g8_fresh_lane();
+        const int lrow = fl >> 3, lpc = fl & 7;       // (shadow the kernel-scope copies: recomputed per tile, see g8_fresh_lane)
         int tm, tn;
         const int tile = (int)blockIdx.x + ((phi && item == ntl) ? 0 : item) * (int)gridDim.x;
         tile_coords(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
@@ -454,7 +474,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         if (TRANS && p.bias && wave == 0) {
             (void)swap_;
             const unsigned char* src = uniform_ptr(reinterpret_cast<const unsigned char*>(p.bias + n0_));
-            const unsigned boff = lane * 16;
+            const unsigned boff = (unsigned)g8_fresh_lane() * 16u;
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + G8_BIAS + slot * 1024);
             G8_DMA(boff, src, dst);
         }
@@ -540,7 +560,9 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
                 G8_BAR8(); G8_MMQ8(F1, FY, sA1, sWO, 1, 0); G8_BAR8();
             }
         } else {
+        G8_STAMP(0);
         G8_VMCNT(8);                                // E has landed (O may still be in flight); older epilogue stores have drained
+        G8_STAMP(1);
         G8_BAR();
         if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }
         if (wr == 1) G8_BAR();                      // stagger the second wave group by one barrier
@@ -575,26 +597,29 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
         }
         }
+        G8_STAMP(2);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (wr == 0) G8_BAR();                      // re-align the wave groups: every LDS read has retired
+        G8_STAMP(3);
 
         const int em0 = m0, en0 = n0; const bool eswap = swap;
         const bool has_next = item + 1 < nitems;
         const bool park_it = PSHIFT && phi && item == 0, unpark_it = PSHIFT && phi && item == ntl;
         // bias of this lane's outputs from the tile's LDS slot (staged with the tile's first DMA group)
         float bv[16];
+        const int elane = g8_fresh_lane();          // the epilogue's own copy of the lane id (see g8_fresh_lane)
         if (TRANS) {
             const float* bs = reinterpret_cast<const float*>(smem8 + G8_BIAS + slot * 1024);
             if (!eswap) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 b4 = (f32x4)(0.f);
-                    if (p.bias) b4 = *reinterpret_cast<const f32x4*>(bs + wc * 64 + (lane >> 4) * 16 + q * 4);
+                    if (p.bias) b4 = *reinterpret_cast<const f32x4*>(bs + wc * 64 + (elane >> 4) * 16 + q * 4);
                     bv[q * 4 + 0] = b4[0]; bv[q * 4 + 1] = b4[1]; bv[q * 4 + 2] = b4[2]; bv[q * 4 + 3] = b4[3];
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { bv[i] = p.bias ? bs[wr * 128 + i * 16 + (lane & 15)] : 0.f; bv[8 + i] = 0.f; }
+                for (int i = 0; i < 8; ++i) { bv[i] = p.bias ? bs[wr * 128 + i * 16 + (elane & 15)] : 0.f; bv[8 + i] = 0.f; }
             }
         }
         // Epilogues that read a residual issue the next tile's DMA after their last load (VMEM loads retire in order: a
@@ -607,8 +632,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         if constexpr (PSHIFT) {
             // lane-linear scratch image [wave][fragment][lane] of f32x4: every instruction moves 1 KiB; written and read by the same lanes
             if (park_it) {                          // K tiles [phi, nk) of the first tile: keep the partial sums, no epilogue
-                int lo = lane * 4;                  // (opaque: the 32 addresses below are loop invariant and would be hoisted out of the
-                asm volatile("" : "+v"(lo));        //  item loop into 64 spilled VGPRs)
+                const int lo = g8_fresh_lane() * 4; // (opaque: the 32 addresses below are loop invariant and would be hoisted out of the item loop)
                 float* pk = p.park + ((size_t)blockIdx.x * 256 + (size_t)wave * 32) * 256 + lo;
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
@@ -624,11 +648,11 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         const float* parked = nullptr;
         if constexpr (PSHIFT) {
             if (unpark_it) {
-                int lo = lane * 4;
-                asm volatile("" : "+v"(lo));
+                const int lo = g8_fresh_lane() * 4;
                 parked = p.park + ((size_t)blockIdx.x * 256 + (size_t)wave * 32) * 256 + lo;
             }
         }
+        G8_STAMP(4);
         if (no_epi) {      // experiment: keep the accumulators live, one store per lane
             float t = 0.f;
 #pragma unroll
@@ -638,8 +662,9 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             reinterpret_cast<half_t*>(p.out)[(long)(em0 + wr * 128 + (lane >> 4)) * p.ldc + en0 + wc * 64 + (lane & 15)] = (half_t)t;
             if (has_next && !dma_first) { tile_setup(item + 1, m0, n0, swap); stage_prologue(n0, swap, slot ^ 1); }
         } else if (TRANS) {
-            if (eswap) epilogue8_vt(p, acc, bv, en0 + wr * 128, em0 + wc * 64, lane);
-            else epilogue8_direct<OMODE>(p, acc, bv, em0 + wr * 128, en0 + wc * 64, lane, reinterpret_cast<const float*>(smem8 + G8_LUT), parked);
+            if (eswap) epilogue8_vt(p, acc, bv, en0 + wr * 128, em0 + wc * 64, elane);
+            else epilogue8_direct<OMODE>(p, acc, bv, em0 + wr * 128, en0 + wc * 64, elane, reinterpret_cast<const float*>(smem8 + G8_LUT), parked);
+            G8_STAMP(5);
             if (has_next && !dma_first) {
                 tile_setup(item + 1, m0, n0, swap);
                 stage_prologue(n0, swap, slot ^ 1);
@@ -659,6 +684,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 
 // Scratch of the phase-shifted walk: 256 KB per workgroup, one buffer per stream (launches of one stream are ordered; the forward
 // runs all its GEMMs on one stream).  Allocated on first use, kept for the life of the process.
+}  // namespace
 float* park_scratch(hipStream_t stream, int grid) {
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, std::pair<float*, int>> ws;
@@ -675,6 +701,20 @@ float* park_scratch(hipStream_t stream, int grid) {
     }
     return e.first;
 }
+namespace {
+
+#ifdef CVA_ABLATION
+}  // namespace
+}  // namespace cva
+// experiment (ablation builds only, not part of the C ABI): copy the timeline stamps of the last stamped launch on the null stream to the host
+extern "C" int cv_dbg_gemm_stamps(long long* dst, int n) {
+    float* src = cva::park_scratch(nullptr, 1);
+    if (!src || hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpy(dst, src, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+namespace cva {
+namespace {
+#endif
 
 template <int OMODE, int TRANS, int ABL, int F8 = 0, int CV3 = 0>
 int launch8(const GemmParams& p, hipStream_t stream) {
@@ -703,7 +743,7 @@ int launch8(const GemmParams& p, hipStream_t stream) {
         const int nk = p.K / G8_BK;
         bool want = p.out_f32 || p.res;
         if (mode == 0) want = false; else if (mode == 1) want = true;
-        q.park = (want && tiles >= 2 * grid && nk >= 8 && grid % 8 == 0) ? park_scratch(stream, grid) : nullptr;
+        q.park = ((want || (p.dbg & 32768)) && tiles >= 2 * grid && nk >= 8 && grid % 8 == 0) ? park_scratch(stream, grid) : nullptr;
         hipLaunchKernelGGL((gemm8_kernel<OMODE, TRANS, ABL, F8, CV3>), dim3(grid), dim3(G8_NT), G8_LDS, stream, q);
         return (int)hipGetLastError();
     }

@@ -81,6 +81,68 @@ __device__ __forceinline__ f32x2_t gelu_lut_pair(const f32x2_t x, const unsigned
     return x * __builtin_elementwise_fma(fr, D, T);
 }
 
+// A wave-uniform divisor, opaque to the optimiser: the magic-number reciprocal of `x / d` with a loop-invariant d is otherwise hoisted out of the
+// persistent tile loop, kept live in a VGPR across the K loop (which needs all 256) and spilled — every reload at a tile boundary is a scratch load
+// + s_waitcnt vmcnt(0) behind the next tile's prologue DMA or the epilogue's stores (gemm8.hip g8_fresh_lane).  Re-deriving it costs ~10 VALU per tile.
+__device__ __forceinline__ int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
+
+// Lean row loops for the hot linear flavours (fp16 out with GELU / ReLU / no activation: fc1, proj, patch, the decoder's 3x3 convolutions;
+// fp32 out + fp32 residual of the same row: fc2).  The general loop of epilogue8_direct keeps ~10 run-time options alive per fragment row (row remaps with integer
+// divisions, residual row modulo, output type, three activations, parked sums): measured 6.2 us per 256 x 256 tile with NO activation
+// against 0.9 us of store issue (profiles/r04_m_gemm_timeline.txt) — instruction count and branch chains, not memory.  Here the options
+// are decided once per tile and the row loop is straight-line code on one running pointer.
+template <int ACT>
+__device__ __forceinline__ void lin_rows_f16(const GemmParams& p, f32x4 (&acc)[8][4], const float (&bv)[16], const int row0, const int n,
+                                             const unsigned lut_lds) {
+    half_t* o = reinterpret_cast<half_t*>(p.out) + (long)row0 * p.ldc + n;
+    const long step = 16L * p.ldc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i, o += step) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2_t xin = {acc[i][j][r] + bv[j * 4 + r], acc[i][j][r + 1] + bv[j * 4 + r + 1]};
+                f32x2_t y = xin;
+                if (ACT == ACT_GELU) y = gelu_lut_pair(xin, lut_lds);
+                if (ACT == ACT_RELU) { y[0] = fmaxf(xin[0], 0.f); y[1] = fmaxf(xin[1], 0.f); }
+                v[j * 4 + r] = y[0]; v[j * 4 + r + 1] = y[1];
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            half8_t w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = (half_t)v[q * 8 + e];
+            *reinterpret_cast<half8_t*>(o + q * 8) = w;
+        }
+    }
+}
+
+__device__ __forceinline__ void lin_rows_f32_res(const GemmParams& p, f32x4 (&acc)[8][4], const float (&bv)[16], const int row0, const int n) {
+    float* o = reinterpret_cast<float*>(p.out) + (long)row0 * p.ldc + n;
+    const float* rp = p.res + (long)row0 * p.ldres + n;
+    const long step = 16L * p.ldc, rstep = 16L * p.ldres;
+    f32x4 r4[2][4];                                     // the residual of row i + 1 is in flight while row i is added and stored
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r4[0][q] = *reinterpret_cast<const f32x4*>(rp + q * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i, o += step) {
+        rp += rstep;
+        if (i + 1 < 8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r4[(i + 1) & 1][q] = *reinterpret_cast<const f32x4*>(rp + q * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = (acc[i][q][r] + bv[q * 4 + r]) + r4[i & 1][q][r];
+            *reinterpret_cast<f32x4*>(o + q * 4) = w;
+        }
+    }
+}
+
 // Direct epilogue for the TRANSPOSED accumulator orientation (C^T fragments: lane (g, li) holds, for row
 // m = i*16 + li of the wave block, the 16 CONSECUTIVE columns g*16 .. g*16+15 — the W rows are permuted at DMA
 // time to make them consecutive).  No LDS: bias / activation / residual on registers, 16-byte stores.
@@ -93,13 +155,32 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
     const int g = lane >> 4, li = lane & 15;
     const int n = ncol0 + g * 16;
     if (p.n_valid && n >= p.n_valid) return;            // padded columns (no cross-lane operation below: OUT_MX8 never runs padded)
+    if constexpr (OMODE == OUT_LINEAR) {
+        bool plain_rows = p.o_rpi <= 0 && p.res_mod <= 0 && parked == nullptr;
+#ifdef CVA_ABLATION
+        plain_rows = plain_rows && !(p.dbg & (512 | 1024 | 4096 | 8192 | 16384 | 65536));      // store experiments + 65536 = the general loop
+#endif
+        if (plain_rows) {
+            const unsigned lut_lds = (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)lut;
+            if (!p.res && !p.out_f32) {
+                if (p.act == ACT_GELU) { lin_rows_f16<ACT_GELU>(p, acc, bv, mrow0 + li, n, lut_lds); return; }
+                if (p.act == ACT_NONE) { lin_rows_f16<ACT_NONE>(p, acc, bv, mrow0 + li, n, lut_lds); return; }
+                lin_rows_f16<ACT_RELU>(p, acc, bv, mrow0 + li, n, lut_lds);          // (the 3x3 convolutions of the decoder)
+                return;
+            } else if (p.res && p.out_f32 && p.act == ACT_NONE) {
+                lin_rows_f32_res(p, acc, bv, mrow0 + li, n);
+                return;
+            }
+        }
+    }
     half_t* qk = nullptr;
     long col_term = 0;
     if (OMODE == OUT_QKV) {
         const int nn = n + p.n_off;
-        const int which = nn / p.D;
-        const int c = nn - which * p.D;
-        const int h = c / p.hd, d = c - h * p.hd;           // 16 consecutive d inside one head (hd % 16 == 0)
+        const int D_ = opaque_s(p.D), hd_ = opaque_s(p.hd);
+        const int which = nn / D_;
+        const int c = nn - which * D_;
+        const int h = c / hd_, d = c - h * hd_;             // 16 consecutive d inside one head (hd % 16 == 0)
         qk = reinterpret_cast<half_t*>(which == 0 ? p.q_out : (which == 1 ? p.k_out : p.vt_out));         // which == 2: row-major v (p.v_rm)
         col_term = (long)h * p.L * p.hd + d;
     }
@@ -110,32 +191,34 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
     const bool fwin = p.win > 0 && p.gw <= 4096 && p.gh <= 4096 && p.win <= 256;
     if (OMODE == OUT_QKV) {
         const int m_first = mrow0 + li;
-        tb = m_first / p.ntok; tt = m_first - tb * p.ntok;
-        if (p.win > 0) { tgy = tt / p.gw; tgx = tt - tgy * p.gw; }
+        const int ntok_ = opaque_s(p.ntok), gw_ = opaque_s(p.gw);
+        tb = m_first / ntok_; tt = m_first - tb * ntok_;
+        if (p.win > 0) { tgy = tt / gw_; tgx = tt - tgy * gw_; }
     }
     // OUT_CONVT: input pixel m -> (image cb, row cy, column cx), likewise walked 16 pixels per fragment row: the two integer divisions per row
     // were ~560 of the ~1000 VALU instructions of this epilogue per tile and wave, next to 128-256 MFMAs for the K = 128 / 256 layers
     int cb = 0, cy = 0, cx = 0, ccout = 1, cdd = 0, cco = 0;
     if (OMODE == OUT_CONVT) {
-        const int m_first = mrow0 + li, hw = p.H * p.Wd;
+        const int m_first = mrow0 + li, hw = opaque_s(p.H * p.Wd), wd_ = opaque_s(p.Wd);
         cb = m_first / hw;
         const int r2 = m_first - cb * hw;
-        cy = r2 / p.Wd; cx = r2 - cy * p.Wd;
-        ccout = p.N >> 2; cdd = n / ccout; cco = n - cdd * ccout;
+        cy = r2 / wd_; cx = r2 - cy * wd_;
+        ccout = opaque_s(p.N >> 2); cdd = n / ccout; cco = n - cdd * ccout;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = mrow0 + i * 16 + li;
         float v[16];
         f32x4 a[4];
-        if (parked) {
+        if (OMODE == OUT_LINEAR && parked) {            // (only linear launches walk phase-shifted)
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = acc[i][j] + __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(parked + (i * 4 + j) * 256));
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = acc[i][j];
         }
-        if (p.act == ACT_GELU) {                        // (uniform branches: one activation's code per launch, no selects)
+        const int act = OMODE == OUT_QKV ? (int)ACT_NONE : p.act;      // (the qkv projection has no activation)
+        if (act == ACT_GELU) {                          // (uniform branches: one activation's code per launch, no selects)
             const unsigned lut_lds = (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)lut;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -145,7 +228,7 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
                     const f32x2_t y = gelu_lut_pair(xin, lut_lds);
                     v[j * 4 + r] = y[0]; v[j * 4 + r + 1] = y[1];
                 }
-        } else if (p.act == ACT_RELU) {
+        } else if (act == ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -158,9 +241,9 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
         }
         if (OMODE == OUT_LINEAR) {
             long orow = m;
-            if (p.o_rpi > 0) orow = (long)m + (long)(m / p.o_rpi) * p.o_extra + p.o_off;
+            if (p.o_rpi > 0) orow = (long)m + (long)(m / opaque_s(p.o_rpi)) * p.o_extra + p.o_off;
             if (p.res) {
-                const long rrow = p.res_mod > 0 ? (long)(m % p.res_mod) : orow;
+                const long rrow = p.res_mod > 0 ? (long)(m % opaque_s(p.res_mod)) : orow;
                 const float* rp = p.res + rrow * p.ldres + n;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -312,7 +395,8 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
     const int g = lane >> 4, li = lane & 15;
     const int mb = mcol0 + g * 16;                               // first of this lane's 16 tokens
     half_t* vt = reinterpret_cast<half_t*>(p.vt_out);
-    const int b0 = mb / p.ntok, t0 = mb - b0 * p.ntok;
+    const int ntok_ = opaque_s(p.ntok);
+    const int b0 = mb / ntok_, t0 = mb - b0 * ntok_;
     const int mlim = p.m_valid ? p.m_valid : 0x7fffffff;        // padded token rows are dropped
     if (mb >= mlim) return;
     const bool fast = p.win == 0 && t0 + 15 < p.ntok && (t0 & 7) == 0 && mb + 15 < mlim;
@@ -368,7 +452,8 @@ __device__ __forceinline__ void epilogue8_vt(const GemmParams& p, f32x4 (&acc)[8
         }
     }
     const int c0 = nrow0 + li + p.n_off - 2 * p.D;              // v column of fragment row 0; +16 per fragment row
-    int h = c0 / p.hd, d = c0 - h * p.hd;
+    const int hd_ = opaque_s(p.hd);
+    int h = c0 / hd_, d = c0 - h * hd_;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float bv = bvt[i];
