@@ -267,6 +267,9 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             Wb = reinterpret_cast<const unsigned char*>(p.W) + (long)n0 * p.ldw * 2;
             return;
         }
+        // (opaque: the 64-bit row pitches are loop invariant and would otherwise be kept across the K loop — in VGPRs, the SGPR file being
+        //  full — and spilled, like the lane id)
+        const long lda_b = (long)g8::opaque_s(p.lda) * ESZ, ldw_b = (long)g8::opaque_s(p.ldw) * ESZ;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave * 32 + i * 8 + lrow;
@@ -276,16 +279,16 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             const int prow = TRANS == 1 ? ((row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3)) : row;
             const long ar0 = a_row(m0);
             if (!swap) {
-                a_voff[i] = (unsigned)((a_row(m0 + row) - ar0) * (long)p.lda * ESZ) + lp * 16;
-                w_voff[i] = (unsigned)((long)prow * p.ldw * ESZ) + lp * 16;
+                a_voff[i] = (unsigned)((a_row(m0 + row) - ar0) * lda_b) + lp * 16;
+                w_voff[i] = (unsigned)((long)prow * ldw_b) + lp * 16;
             } else {
-                a_voff[i] = (unsigned)((long)row * p.ldw * ESZ) + lp * 16;
-                w_voff[i] = (unsigned)((a_row(m0 + prow) - ar0) * (long)p.lda * ESZ) + lp * 16;
+                a_voff[i] = (unsigned)((long)row * ldw_b) + lp * 16;
+                w_voff[i] = (unsigned)((a_row(m0 + prow) - ar0) * lda_b) + lp * 16;
             }
         }
         {
-            const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.A) + a_row(m0) * (long)p.lda * ESZ;
-            const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.W) + (long)n0 * p.ldw * ESZ;
+            const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.A) + a_row(m0) * lda_b;
+            const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.W) + (long)n0 * ldw_b;
             Ab = swap ? wbase : abase;
             Wb = swap ? abase : wbase;
         }

@@ -143,6 +143,42 @@ __device__ __forceinline__ void lin_rows_f32_res(const GemmParams& p, f32x4 (&ac
     }
 }
 
+// Lean rows of the fused qkv projection (q / k columns, and v when the layer keeps V row-major): token -> (sequence, position) walked 16
+// tokens per fragment row with selects only.  Holds when the token count of an image and (window layers) the grid width are multiples of
+// 16 — the lane's tokens m0 + li + 16 i then keep their residue mod 16, a step never skips a grid row and an image ends on a row end — and no
+// token rows are padded.  The general loop below covers everything else (ViT-S: 4097 tokens).
+template <bool WIN>
+__device__ __forceinline__ void qkv_rows(const GemmParams& p, f32x4 (&acc)[8][4], const float (&bv)[16], half_t* qk, const long col_term,
+                                         const int m_first) {
+    const int ntok = opaque_s(p.ntok);
+    int tb = m_first / ntok, tt = m_first - tb * ntok, tgy = 0, tgx = 0;
+    const int gw = p.gw, win = opaque_s(p.win);
+    const float inv_win = 1.0f / (float)(WIN ? win : 1);
+    if (WIN) { const int gw_ = opaque_s(gw); tgy = tt / gw_; tgx = tt - tgy * gw_; }
+    const long hl = (long)p.heads * p.L;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int s_ = tb, pos = tt;
+        if (WIN) {                                      // window index by float reciprocal: exact for coordinate * win < 2^21 (caller)
+            const int wy = (int)(((float)tgy + 0.5f) * inv_win), wx = (int)(((float)tgx + 0.5f) * inv_win);
+            s_ = (tb * p.nwy + wy) * p.nwx + wx;
+            pos = (tgy - wy * win) * win + (tgx - wx * win);
+        }
+        half_t* o = qk + ((long)s_ * hl + pos) * p.hd + col_term;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            half8_t w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = (half_t)(acc[i][q * 2 + (e >> 2)][e & 3] + bv[q * 8 + e]);
+            *reinterpret_cast<half8_t*>(o + q * 8) = w;
+        }
+        tt += 16;
+        if (WIN) { tgx += 16; const bool wr = tgx >= gw; tgx = wr ? tgx - gw : tgx; tgy = wr ? tgy + 1 : tgy; }
+        const bool wi = tt >= ntok;                     // next image: its first grid row, column = the new token index (< 16 <= gw)
+        tt = wi ? tt - ntok : tt; tb = wi ? tb + 1 : tb; tgy = wi ? 0 : tgy;
+    }
+}
+
 // Direct epilogue for the TRANSPOSED accumulator orientation (C^T fragments: lane (g, li) holds, for row
 // m = i*16 + li of the wave block, the 16 CONSECUTIVE columns g*16 .. g*16+15 — the W rows are permuted at DMA
 // time to make them consecutive).  No LDS: bias / activation / residual on registers, 16-byte stores.
@@ -184,10 +220,23 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
         qk = reinterpret_cast<half_t*>(which == 0 ? p.q_out : (which == 1 ? p.k_out : p.vt_out));         // which == 2: row-major v (p.v_rm)
         col_term = (long)h * p.L * p.hd + d;
     }
+    if constexpr (OMODE == OUT_QKV) {
+        bool lean = !p.m_valid && (p.ntok & 15) == 0 && p.ntok >= 16;
+        if (p.win > 0) lean = lean && (p.gw & 15) == 0 && p.ntok == p.gh * p.gw && p.gw <= 4096 && p.gh <= 4096 && p.win <= 256;
+#ifdef CVA_ABLATION
+        lean = lean && !(p.dbg & 65536);                // (A/B: the general loop)
+#endif
+        if (lean) {
+            if (p.win > 0) qkv_rows<true>(p, acc, bv, qk, col_term, mrow0 + li);
+            else qkv_rows<false>(p, acc, bv, qk, col_term, mrow0 + li);
+            return;
+        }
+    }
     // OUT_QKV: token m -> (image b, token t, grid row gy, grid col gx), advanced by 16 tokens per fragment row without
     // integer divisions; the window index of a grid coordinate is a float reciprocal (exact: coordinate * win < 2^21)
     int tb = 0, tt = 0, tgy = 0, tgx = 0;
-    const float inv_win = 1.0f / (float)(p.win > 0 ? p.win : 1);
+    const int win_o = opaque_s(p.win);                  // (opaque: 1 / win is loop invariant, see opaque_s)
+    const float inv_win = 1.0f / (float)(win_o > 0 ? win_o : 1);
     const bool fwin = p.win > 0 && p.gw <= 4096 && p.gh <= 4096 && p.win <= 256;
     if (OMODE == OUT_QKV) {
         const int m_first = mrow0 + li;
@@ -366,7 +415,7 @@ __device__ __forceinline__ void epilogue8_direct(const GemmParams& p, f32x4 (&ac
             tt += 16; tgx += 16;
             if (tt >= p.ntok) {
                 tt -= p.ntok; ++tb;
-                if (p.win > 0) { tgy = tt / p.gw; tgx = tt - tgy * p.gw; }
+                if (p.win > 0) { const int gw_ = opaque_s(p.gw); tgy = tt / gw_; tgx = tt - tgy * gw_; }
             } else if (p.win > 0) {
                 while (tgx >= p.gw) { tgx -= p.gw; ++tgy; }
             }

@@ -149,6 +149,35 @@ __global__ void k_comp_stats(const int* __restrict__ Lb, int* __restrict__ csize
     }
 }
 
+// Run walks without loops, for W % 64 == 0 (a wave = 64 consecutive pixels of one row, as in k_cc_init_runs): a run's length inside the chunk
+// comes out of the wave's ballot mask, so the lane at a run's start needs no dependent loads — the kernels above let that lane walk its run
+// pixel by pixel (a load per step, the other 63 lanes idle).  A run that crosses a chunk seam is accounted as two pieces; every accumulator
+// is an integer sum / min / max, so the result is the same.  (profiles/r04_r_postproc_alone_kernel_stats.csv: k_comp_stats 814 us,
+// k_marker_ids 610 us, k_inst_stats 1596 us per 64 tiles before.)
+__device__ __forceinline__ int run_len_from(unsigned long long m, int lane) {     // bit `lane` of m is set: consecutive set bits from there
+    const unsigned long long z = ~(m >> lane);
+    return z ? __ffsll((long long)z) - 1 : 64 - lane;
+}
+
+__global__ void k_comp_stats_runs(const int* __restrict__ Lb, int* __restrict__ csize, int* __restrict__ bb, int H, int W) {
+    const int N = H * W, lane = threadIdx.x & 63;
+    const long base = (long)blockIdx.y * N;
+    const int* L = Lb + base;
+    int* cs = csize + base;
+    int* y0 = bb + base * 4; int* y1 = y0 + N; int* x0 = y1 + N; int* x1 = x0 + N;
+    for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < N; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + lane;
+        const int r = L[i];
+        const unsigned long long m = __ballot(r >= 0);
+        if (r >= 0 && (lane == 0 || !((m >> (lane - 1)) & 1ull))) {
+            const int len = run_len_from(m, lane);
+            const int y = i / W, x = i - y * W;
+            atomicAdd(&cs[r], len);
+            atomicMin(&y0[r], y); atomicMax(&y1[r], y); atomicMin(&x0[r], x); atomicMax(&x1[r], x + len - 1);
+        }
+    }
+}
+
 // blb = fg && size >= 10 (hard-wired, post_proc:182); surviving roots are queued for the flood.  The flood of a component is a
 // sequential chain (one pop per pixel), so the batch ends when the LARGEST components end: components of >= FLOOD_BIG pixels go to the
 // front of the tile's list (filled from slot 0 up), the rest to the back (filled from the last slot down), and the flood's waves are
@@ -288,6 +317,81 @@ __global__ void k_sobel_col(const double* __restrict__ tmp_h, const double* __re
     }
 }
 
+// Four outputs per thread off one register window (W, H multiples of 4).  The two kernels above spend their time on addresses — a
+// reflect101 loop and 64-bit index arithmetic per tap, 42 / 40 loads per pixel — not on the 84 / 62 fp64 operations (round-4 profile of the chain
+// alone, profiles/r04_r_postproc_alone_kernel_stats.csv: 1161 + 1567 us per 64 tiles for 2.7 GB of traffic).  Here a thread loads the
+// KS + 3 source values its four outputs share ONCE, interior threads without any border arithmetic; every output is the same chain of
+// roundings as above (same products, same order of additions), so the results are bit-identical.
+template <int KS>
+__global__ void k_sobel_row4(const float* __restrict__ hv, const double* __restrict__ params, const SobelTaps taps,
+                             double* __restrict__ tmp_h, double* __restrict__ tmp_v, int H, int W) {
+    constexpr int R = KS / 2;
+    const int N = H * W, tile = blockIdx.y, Wq = W >> 2;
+    const float* h = hv + (long)tile * 2 * N;
+    const float* v = h + N;
+    const float ah = (float)params[(tile * 2 + 0) * 2], bh = (float)params[(tile * 2 + 0) * 2 + 1];
+    const float av = (float)params[(tile * 2 + 1) * 2], bv = (float)params[(tile * 2 + 1) * 2 + 1];
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < (N >> 2); q += gridDim.x * blockDim.x) {
+        const int y = q / Wq, x0 = (q - y * Wq) << 2;
+        const bool interior = x0 - R >= 0 && x0 + 3 + R < W;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const float* row = (pl ? v : h) + (long)y * W;
+            const float a = pl ? av : ah, b = pl ? bv : bh;
+            double win[KS + 3];
+#pragma unroll
+            for (int k = 0; k < KS + 3; ++k) {
+                const int xx = interior ? x0 - R + k : reflect101(x0 - R + k, W);
+                win[k] = (double)fmaf(row[xx], a, b);
+            }
+            double o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double acc = (pl ? taps.s[0] : taps.d[0]) * win[u];
+#pragma unroll
+                for (int j = 1; j < KS; ++j) acc += (pl ? taps.s[j] : taps.d[j]) * win[u + j];
+                o[u] = acc;
+            }
+            double* dst = (pl ? tmp_v : tmp_h) + (long)tile * N + (long)y * W + x0;
+            *reinterpret_cast<double2*>(dst) = make_double2(o[0], o[1]);
+            *reinterpret_cast<double2*>(dst + 2) = make_double2(o[2], o[3]);
+        }
+    }
+}
+
+template <int KS>
+__global__ void k_sobel_col4(const double* __restrict__ tmp_h, const double* __restrict__ tmp_v, const SobelTaps taps,
+                             double* __restrict__ sob, int H, int W) {
+    constexpr int R = KS / 2;
+    const int N = H * W, tile = blockIdx.y;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < (N >> 2); q += gridDim.x * blockDim.x) {
+        const int yb = q / W, x = q - yb * W, y0 = yb << 2;              // consecutive threads: consecutive columns of four rows
+        const bool interior = y0 - R >= 0 && y0 + 3 + R < H;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const double* src = (pl ? tmp_v : tmp_h) + (long)tile * N + x;
+            double win[KS + 3];
+#pragma unroll
+            for (int k = 0; k < KS + 3; ++k) {
+                const int yy = interior ? y0 - R + k : reflect101(y0 - R + k, H);
+                win[k] = src[(long)yy * W];
+            }
+            double* dst = sob + ((long)tile * 2 + pl) * N + (long)y0 * W + x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double acc = pl ? 0.0 : taps.s[R] * win[u + R];
+#pragma unroll
+                for (int j = 1; j <= R; ++j) {
+                    // (up = row y + j, dn = row y - j, as above)
+                    if (pl) acc += taps.d[R + j] * (win[u + R + j] - win[u + R - j]);
+                    else acc += taps.s[R + j] * (win[u + R + j] + win[u + R - j]);
+                }
+                dst[(long)u * W] = acc;
+            }
+        }
+    }
+}
+
 // post_proc:208-240: renormalise, 1 - x (float32), max, -(1 - blb) (-> float64), clip, dist0, marker seed
 __global__ void k_combine(const double* __restrict__ sob, const double* __restrict__ params,
                           const uint8_t* __restrict__ blb, double* __restrict__ d0, uint8_t* __restrict__ mk, int N) {
@@ -378,6 +482,37 @@ __global__ void k_morph5(const uint8_t* __restrict__ in, uint8_t* __restrict__ o
     }
 }
 
+// The same structuring element on FOUR pixels per thread: the planes hold 0 / 1 bytes, so erosion / dilation of packed bytes is a bitwise
+// AND / OR of byte-shifted words (v_alignbyte_b32 over the left / centre / right words of a row); 11 word loads per 4 pixels instead of 68 byte
+// loads behind 17 border tests each (620 us per 64 tiles for 134 MB, profiles/r04_r_postproc_alone_kernel_stats.csv).  W a multiple of 4.
+template <bool ERODE>
+__global__ void k_morph5_w4(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H, int W) {
+    const int N = H * W, Ww = W >> 2;
+    const unsigned* s = reinterpret_cast<const unsigned*>(in + (long)blockIdx.y * N);
+    unsigned* o = reinterpret_cast<unsigned*>(out + (long)blockIdx.y * N);
+    constexpr unsigned neutral = ERODE ? 0x01010101u : 0u;         // pixels outside the image are ignored
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (N >> 2); i += gridDim.x * blockDim.x) {
+        const int y = i / Ww, xw = i - y * Ww;
+        unsigned acc = neutral;
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            const unsigned* r = s + (long)yy * Ww;
+            const unsigned w1 = r[xw];
+            unsigned v = w1;
+            if (dy != -2 && dy != 2) {
+                const unsigned w0 = xw > 0 ? r[xw - 1] : neutral, w2 = xw + 1 < Ww ? r[xw + 1] : neutral;
+                const unsigned m2 = __builtin_amdgcn_alignbyte(w1, w0, 2), m1 = __builtin_amdgcn_alignbyte(w1, w0, 3);
+                const unsigned p1 = __builtin_amdgcn_alignbyte(w2, w1, 1), p2 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+                v = ERODE ? (w1 & m2 & m1 & p1 & p2) : (w1 | m2 | m1 | p1 | p2);
+            }
+            acc = ERODE ? (acc & v) : (acc | v);
+        }
+        o[i] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // raster-order ids: exclusive scan of the root flags (scipy.ndimage.label numbering)
 // ------------------------------------------------------------------------------------------------
@@ -456,6 +591,24 @@ __global__ void k_marker_ids(const int* __restrict__ Lb, const int* __restrict__
 }
 
 // remove_small_objects(marker, object_size) (no relabel) and inst = markers * mask (skimage _validate_inputs)
+__global__ void k_marker_ids_runs(const int* __restrict__ Lb, const int* __restrict__ rank, int* __restrict__ marker,
+                                  int* __restrict__ msize, int N, int W, int max_ids) {      // W % 64 == 0, see run_len_from
+    const long base = (long)blockIdx.y * N;
+    const int lane = threadIdx.x & 63;
+    for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < N; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + lane;
+        const int r = Lb[base + i];
+        const unsigned long long m = __ballot(r >= 0);
+        int id = 0;
+        if (r >= 0) {
+            id = rank[base + r];
+            if (id <= max_ids && (lane == 0 || !((m >> (lane - 1)) & 1ull)))
+                atomicAdd(&msize[(long)blockIdx.y * (max_ids + 1) + id], run_len_from(m, lane));
+        }
+        marker[base + i] = id;
+    }
+}
+
 __global__ void k_marker_filter(int* __restrict__ marker, const int* __restrict__ msize, int object_size,
                                 const uint8_t* __restrict__ blb, int* __restrict__ inst, int N, int max_ids) {
     const long base = (long)blockIdx.y * N;
@@ -738,6 +891,47 @@ __global__ void k_inst_stats(int* __restrict__ inst, const uint8_t* __restrict__
         atomicMin(&st.first[sb + id], i);
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (h[k]) atomicAdd(&st.hist[(sb + id) * 8 + k], h[k]);
+    }
+    if (__any(zero_seen) && (threadIdx.x & 63) == 0) st.has_zero[tile] = 1;
+}
+
+__global__ void k_inst_stats_runs(int* __restrict__ inst, const uint8_t* __restrict__ type, StatArrays st, int H, int W,
+                                  int max_ids, int nr_types) {                                 // W % 64 == 0, see run_len_from
+    const int N = H * W, tile = blockIdx.y, lane = threadIdx.x & 63;
+    const long base = (long)tile * N, sb = (long)tile * (max_ids + 1);
+    bool zero_seen = false;
+    for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < N; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + lane;
+        const int id = inst[base + i];
+        if (id <= 0) { zero_seen = true; if (id < 0) inst[base + i] = 0; }
+        const int id_left = __shfl_up(id, 1);
+        const bool valid = id > 0 && id <= max_ids;
+        const unsigned long long bm = __ballot(lane == 0 || id != id_left);        // first pixels of the chunk's runs (any id)
+        unsigned long long tm[8];
+        if (nr_types > 0) {
+            int t = type[base + i]; if (t > 7) t = 7;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tm[k] = __ballot(t == k);
+        }
+        if (valid && ((bm >> lane) & 1ull)) {
+            const unsigned long long above = bm & ~((2ull << lane) - 1ull);
+            const int len = (above ? __ffsll((long long)above) - 1 : 64) - lane;
+            const unsigned long long range = (len == 64 ? ~0ull : ((1ull << len) - 1ull)) << lane;
+            const int y = i / W, x = i - y * W;
+            atomicAdd(&st.cnt[sb + id], len);
+            atomicAdd(&st.sx[sb + id], (unsigned long long)len * x + (unsigned long long)len * (len - 1) / 2);
+            atomicAdd(&st.sy[sb + id], (unsigned long long)len * y);
+            atomicMin(&st.rmin[sb + id], y); atomicMax(&st.rmax[sb + id], y);
+            atomicMin(&st.cmin[sb + id], x); atomicMax(&st.cmax[sb + id], x + len - 1);
+            atomicMin(&st.first[sb + id], i);
+            if (nr_types > 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned c = (unsigned)__popcll(tm[k] & range);
+                    if (c) atomicAdd(&st.hist[(sb + id) * 8 + k], c);
+                }
+            }
+        }
     }
     if (__any(zero_seen) && (threadIdx.x & 63) == 0) st.has_zero[tile] = 1;
 }
@@ -1072,7 +1266,8 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
         else hipLaunchKernelGGL(k_cc_flatten<0>, grid, blk, 0, st, L, N, w->csize, w->bb, w->flag);
     };
     cc(bin, 0, w->L1, 1);
-    hipLaunchKernelGGL(k_comp_stats, grid, blk, 0, st, w->L1, w->csize, w->bb, H, W);
+    if (runs) hipLaunchKernelGGL(k_comp_stats_runs, grid, blk, 0, st, w->L1, w->csize, w->bb, H, W);
+    else hipLaunchKernelGGL(k_comp_stats, grid, blk, 0, st, w->L1, w->csize, w->bb, H, W);
     int* comp_count = w->counters;            // [B]
     int* queue_head = w->counters + B;        // [B]
     int* big_count = w->counters + 3 * B;     // [B]
@@ -1080,8 +1275,18 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     // ---- P2/P3: min-max normalise (fused) + separable Sobel in fp64 ----
     hipLaunchKernelGGL((k_minmax_partial<float>), dim3(RED_BLOCKS, 2, B), blk, 0, st, hv, 2, N, w->partial);
     hipLaunchKernelGGL(k_minmax_final, dim3(2, B), blk, 0, st, w->partial, 2, w->params_hv);
-    hipLaunchKernelGGL(k_sobel_row, grid, blk, 0, st, hv, w->params_hv, taps, w->tmp_h, w->tmp_v, H, W);
-    hipLaunchKernelGGL(k_sobel_col, grid, blk, 0, st, w->tmp_h, w->tmp_v, taps, w->sob, H, W);
+    const bool quad = (W % 4) == 0 && (H % 4) == 0 && W >= 32 && H >= 32;      // four outputs per thread (see k_sobel_row4)
+    const dim3 gridq(std::min((N / 4 + NT - 1) / NT, 2048), B);
+    if (quad && ksize == 21) {
+        hipLaunchKernelGGL((k_sobel_row4<21>), gridq, blk, 0, st, hv, w->params_hv, taps, w->tmp_h, w->tmp_v, H, W);
+        hipLaunchKernelGGL((k_sobel_col4<21>), gridq, blk, 0, st, w->tmp_h, w->tmp_v, taps, w->sob, H, W);
+    } else if (quad) {
+        hipLaunchKernelGGL((k_sobel_row4<11>), gridq, blk, 0, st, hv, w->params_hv, taps, w->tmp_h, w->tmp_v, H, W);
+        hipLaunchKernelGGL((k_sobel_col4<11>), gridq, blk, 0, st, w->tmp_h, w->tmp_v, taps, w->sob, H, W);
+    } else {
+        hipLaunchKernelGGL(k_sobel_row, grid, blk, 0, st, hv, w->params_hv, taps, w->tmp_h, w->tmp_v, H, W);
+        hipLaunchKernelGGL(k_sobel_col, grid, blk, 0, st, w->tmp_h, w->tmp_v, taps, w->sob, H, W);
+    }
     hipLaunchKernelGGL((k_minmax_partial<double>), dim3(RED_BLOCKS, 2, B), blk, 0, st, w->sob, 2, N, w->partial);
     hipLaunchKernelGGL(k_minmax_final, dim3(2, B), blk, 0, st, w->partial, 2, w->params_sob);
     // ---- P4: combine, blur ----
@@ -1091,15 +1296,21 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     cc(w->mk, 1, w->L2, 2);
     hipLaunchKernelGGL(k_border_flag, dim3((2 * (H + W) + NT - 1) / NT, B), blk, 0, st, w->L2, w->flag, H, W);
     hipLaunchKernelGGL(k_fill, grid, blk, 0, st, w->mk, w->L2, w->flag, w->mk2, N);
-    hipLaunchKernelGGL((k_morph5<true>), grid, blk, 0, st, w->mk2, w->mk, H, W);
-    hipLaunchKernelGGL((k_morph5<false>), grid, blk, 0, st, w->mk, w->mk2, H, W);
+    if (quad) {
+        hipLaunchKernelGGL((k_morph5_w4<true>), gridq, blk, 0, st, w->mk2, w->mk, H, W);
+        hipLaunchKernelGGL((k_morph5_w4<false>), gridq, blk, 0, st, w->mk, w->mk2, H, W);
+    } else {
+        hipLaunchKernelGGL((k_morph5<true>), grid, blk, 0, st, w->mk2, w->mk, H, W);
+        hipLaunchKernelGGL((k_morph5<false>), grid, blk, 0, st, w->mk, w->mk2, H, W);
+    }
     cc(w->mk2, 0, w->L2, 0);
     hipLaunchKernelGGL(k_scan_partial, dim3(w->nblk, B), blk, 0, st, w->L2, N, w->bsum, w->nblk);
     int* nmark = w->counters + 2 * B;         // [B]
     hipLaunchKernelGGL(k_scan_blocks, dim3(B), blk, 0, st, w->bsum, w->nblk, nmark);
     hipLaunchKernelGGL(k_scan_apply, dim3(w->nblk, B), blk, 0, st, w->L2, N, w->bsum, w->nblk, w->rank);
     hipLaunchKernelGGL(k_stats_init, dim3(std::min((d.max_ids + NT) / NT, 32), B), blk, 0, st, w->st, w->msize, nmark, d.max_ids);
-    hipLaunchKernelGGL(k_marker_ids, grid, blk, 0, st, w->L2, w->rank, w->marker, w->msize, N, W, d.max_ids);
+    if (runs) hipLaunchKernelGGL(k_marker_ids_runs, grid, blk, 0, st, w->L2, w->rank, w->marker, w->msize, N, W, d.max_ids);
+    else hipLaunchKernelGGL(k_marker_ids, grid, blk, 0, st, w->L2, w->rank, w->marker, w->msize, N, W, d.max_ids);
     hipLaunchKernelGGL(k_marker_filter, grid, blk, 0, st, w->marker, w->msize, object_size, w->blb, inst_out, N, d.max_ids);
     // ---- P6: ordered flood ----
     FloodParams fp{};
@@ -1110,7 +1321,8 @@ int pp_run(PostprocWorkspace* w, const uint8_t* bin, const uint8_t* type, const 
     { static const int dbg = cva_env_int("CVA_PP_DBG", 0); fp.dbg = dbg; }   // ablation builds only (common.h)
     hipLaunchKernelGGL(k_flood, dim3(B, 1024), dim3(64), 0, st, fp);
     // ---- P7/P8: per-instance records + contours ----
-    hipLaunchKernelGGL(k_inst_stats, grid, blk, 0, st, inst_out, type, w->st, H, W, d.max_ids, nr_types);
+    if (runs) hipLaunchKernelGGL(k_inst_stats_runs, grid, blk, 0, st, inst_out, type, w->st, H, W, d.max_ids, nr_types);
+    else hipLaunchKernelGGL(k_inst_stats, grid, blk, 0, st, inst_out, type, w->st, H, W, d.max_ids, nr_types);
     hipLaunchKernelGGL(k_inst_records, dim3(B), blk, 0, st, w->st, recs, n_recs, d.max_ids, d.max_inst, nr_types, nmark);
     if (nr_types > 8 && vote_wide(w, inst_out, type, B, nr_types, recs, n_recs, nmark, st)) return 1;
     const dim3 cgrid((d.max_inst + 63) / 64 > 64 ? 64 : (d.max_inst + 63) / 64, B);
@@ -1138,7 +1350,8 @@ int pp_records(PostprocWorkspace* w, int32_t* inst_io, const uint8_t* type, int 
     int* nmark = w->counters + 2 * B;         // [B]: here simply "every id slot may be live"
     hipLaunchKernelGGL(k_fill_counts, dim3((B + NT - 1) / NT), blk, 0, st, nmark, B, d.max_ids);
     hipLaunchKernelGGL(k_stats_init, dim3(std::min((d.max_ids + NT) / NT, 32), B), blk, 0, st, w->st, w->msize, nmark, d.max_ids);
-    hipLaunchKernelGGL(k_inst_stats, grid, blk, 0, st, inst_io, type, w->st, H, W, d.max_ids, nr_types);
+    if ((W % 64) == 0) hipLaunchKernelGGL(k_inst_stats_runs, grid, blk, 0, st, inst_io, type, w->st, H, W, d.max_ids, nr_types);
+    else hipLaunchKernelGGL(k_inst_stats, grid, blk, 0, st, inst_io, type, w->st, H, W, d.max_ids, nr_types);
     hipLaunchKernelGGL(k_inst_records, dim3(B), blk, 0, st, w->st, recs, n_recs, d.max_ids, d.max_inst, nr_types, nmark);
     if (nr_types > 8 && vote_wide(w, inst_io, type, B, nr_types, recs, n_recs, nmark, st)) return 1;
     const dim3 cgrid((d.max_inst + 63) / 64 > 64 ? 64 : (d.max_inst + 63) / 64, B);
