@@ -134,9 +134,9 @@ def extras(model, step, B, dev):
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
+    import ctypes as C
+    from cellvit_amd import _lib
     try:
-        import ctypes as C
-        from cellvit_amd import _lib
         model.compute_dtype = "fp8"
         step(); step()                                        # warm-up (builds the fp8 engine's geometry)
         eng8 = model._last_engine
@@ -168,7 +168,16 @@ def extras(model, step, B, dev):
         def step2():
             m2.forward_u8(x2, (0.5,) * 3, (0.5,) * 3, retrieve_tokens=True)
             postprocess_device(pb, pt, ph, 6, 10, 21, want_contours=True)
-        out["vit256_tiles_per_s"] = B / timed(step2)
+        step2(); step2()                                      # warm-up (builds the engine's geometry)
+        eng2 = m2._last_engine
+        _lib.check(eng2.lib.cv_profile_enable(eng2.h, 1))     # per-class roofline of this leg as well
+        out["vit256_tiles_per_s"] = B / timed(step2, n=3, w=0)
+        ms = (C.c_double * NK)(); n = (C.c_int64 * NK)(); fl = (C.c_double * NK)()
+        _lib.check(eng2.lib.cv_profile_collect(eng2.h, ms, n, fl))
+        _lib.check(eng2.lib.cv_profile_enable(eng2.h, 0))
+        out["vit256_kernel_classes"] = {name: {"launches": int(n[i]), "total_ms_per_step": ms[i] / 3, "tflops": fl[i] / (ms[i] * 1e-3) / 1e12,
+                                               "peak_tflops": KPEAK[i], "frac": fl[i] / (ms[i] * 1e-3) / 1e12 / KPEAK[i]}
+                                        for i, name in enumerate(KCLASS) if n[i]}
         out["vit256_note"] = "CellViT-256 fp16, 1024^2 tiles, forward + on-GPU post-processing (BASELINE.json configs[1] + post-processing)"
         del m2, x2, pb, pt, ph
     except Exception as e:      # noqa: BLE001

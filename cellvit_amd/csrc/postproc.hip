@@ -86,15 +86,24 @@ __global__ void k_cc_init_runs(const uint8_t* __restrict__ src, int invert, int*
     }
 }
 
+// (the foreground bits of the left / upper-left neighbours come from the wave's ballots of its own row chunk and of the chunk above — two loads
+//  per pixel instead of four; only lane 0 looks across the chunk seam.  Signs never change while roots are being hooked, so the masks are stable.)
 __global__ void k_cc_merge_runs(int* __restrict__ Lb, int H, int W) {
-    const int N = H * W;
+    const int N = H * W, lane = threadIdx.x & 63;
     int* L = Lb + (long)blockIdx.y * N;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-        if (L[i] < 0) continue;
-        const int y = i / W, x = i - y * W;
-        const bool left = x > 0 && L[i - 1] >= 0;
-        if (left && (x & 63) == 0) uf_union(L, i, i - 1);                    // run continues across a chunk seam
-        if (y > 0 && L[i - W] >= 0 && !(left && L[i - W - 1] >= 0)) uf_union(L, i, i - W);
+    for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < N; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + lane;
+        const int y = i0 / W, xc = i0 - y * W;                               // (wave-uniform: the chunk's row and first column)
+        const bool fg = L[i] >= 0;
+        const bool up = y > 0 && L[i - W] >= 0;
+        const unsigned long long m = __ballot(fg), um = __ballot(up);
+        if (m == 0ull) continue;
+        const bool seam_left = xc > 0 && L[i0 - 1] >= 0, seam_upleft = xc > 0 && y > 0 && L[i0 - W - 1] >= 0;
+        if (!fg) continue;
+        const bool left = lane ? ((m >> (lane - 1)) & 1ull) != 0 : seam_left;
+        const bool upleft = lane ? ((um >> (lane - 1)) & 1ull) != 0 : seam_upleft;
+        if (left && lane == 0) uf_union(L, i, i - 1);                        // run continues across a chunk seam
+        if (up && !(left && upleft)) uf_union(L, i, i - W);
     }
 }
 
@@ -325,7 +334,7 @@ __global__ void k_sobel_col(const double* __restrict__ tmp_h, const double* __re
 template <int KS>
 __global__ void k_sobel_row4(const float* __restrict__ hv, const double* __restrict__ params, const SobelTaps taps,
                              double* __restrict__ tmp_h, double* __restrict__ tmp_v, int H, int W) {
-    constexpr int R = KS / 2;
+    constexpr int R = KS / 2, A = (R + 3) & ~3, N4 = (A + 4 + R + 3) / 4;      // window [x0 - R, x0 + 3 + R] inside N4 aligned float4s from x0 - A
     const int N = H * W, tile = blockIdx.y, Wq = W >> 2;
     const float* h = hv + (long)tile * 2 * N;
     const float* v = h + N;
@@ -334,15 +343,27 @@ __global__ void k_sobel_row4(const float* __restrict__ hv, const double* __restr
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < (N >> 2); q += gridDim.x * blockDim.x) {
         const int y = q / Wq, x0 = (q - y * Wq) << 2;
         const bool interior = x0 - R >= 0 && x0 + 3 + R < W;
+        const bool wide = x0 - A >= 0 && x0 - A + 4 * N4 <= W;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
             const float* row = (pl ? v : h) + (long)y * W;
             const float a = pl ? av : ah, b = pl ? bv : bh;
             double win[KS + 3];
+            if (wide) {                 // 16-byte loads from the aligned column below x0 - R: consecutive lanes, consecutive float4s
+                float buf[4 * N4];
 #pragma unroll
-            for (int k = 0; k < KS + 3; ++k) {
-                const int xx = interior ? x0 - R + k : reflect101(x0 - R + k, W);
-                win[k] = (double)fmaf(row[xx], a, b);
+                for (int k = 0; k < N4; ++k) {
+                    const float4 f = *reinterpret_cast<const float4*>(row + x0 - A + 4 * k);
+                    buf[4 * k] = f.x; buf[4 * k + 1] = f.y; buf[4 * k + 2] = f.z; buf[4 * k + 3] = f.w;
+                }
+#pragma unroll
+                for (int k = 0; k < KS + 3; ++k) win[k] = (double)fmaf(buf[k + A - R], a, b);
+            } else {
+#pragma unroll
+                for (int k = 0; k < KS + 3; ++k) {
+                    const int xx = interior ? x0 - R + k : reflect101(x0 - R + k, W);
+                    win[k] = (double)fmaf(row[xx], a, b);
+                }
             }
             double o[4];
 #pragma unroll
