@@ -835,6 +835,9 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                     if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
                         q = yy * W + xx;
                         qv = dist[q];                                     // consumed after the NEXT iteration's pool scan
+#ifdef CVA_ABLATION      // timing experiment (wrong flood order): what the dependent global load costs per pop (CVA_PP_DBG & 1)
+                        if (p.dbg & 1) qv = (double)(q & 1023);
+#endif
                         if (use_bits) {
                             if (yy >= by0 && yy <= by1 && xx >= bx0 && xx <= bx1) {
                                 const int loc = (yy - by0) * bw + (xx - bx0);
