@@ -26,6 +26,8 @@
 //   7      (1,1)          A1, X      -                                        O.W <- tile kt+3     vmcnt(4): E complete
 //   8      (1,0)          A1, Y      A0 <- E.A sub 0, X <- E.W sub 0          O.A <- tile kt+3
 //
+// (DMA columns of the table: the schedule of the implicit-GEMM convolutions and of the fp8 variant.  The fp16 linear / qkv launches issue the same sixteen pieces
+//  per wave and iteration TWO per phase, into the sub-tile that became free two phases earlier — table and measurements at the K loop, `BAL`.)
 // Hazard rules the table obeys (barrier epochs, with the half-phase stagger between the wave groups):
 //   WAR  a tile is re-staged >= 2 phases after its last ds_read (E.W: 1 -> 3, E.A: 2 -> 4, O.W: 5 -> 7, O.A: 6 -> 8);
 //   RAW  a staged tile is read >= 1 phase after the counted vmcnt that retires it (O: wait in 3, read from 4;
@@ -96,10 +98,16 @@ __device__ __forceinline__ int g8_fresh_lane() {
 }
 #ifdef CVA_ABLATION      // experiment: per-tile timeline of wave 0 / wave 4 of the first 8 workgroups (CVA_GEMM_DBG & 32768), written to p.park
 #define G8_STAMP(slot)                                                                                                  \
-    do { if ((p.dbg & 32768) && p.park && blockIdx.x < 8 && (wave & 3) == 0 && lane == 0 && item < 24)                  \
+    do { if ((p.dbg & 32768) && !(p.dbg & 262144) && p.park && blockIdx.x < 8 && (wave & 3) == 0 && lane == 0 && item < 24) \
              reinterpret_cast<long long*>(p.park)[((blockIdx.x * 2 + (wave >> 2)) * 24 + item) * 8 + (slot)] = (long long)wall_clock64(); } while (0)
+// CVA_GEMM_DBG & 262144 (with 32768): instead of the tile timeline, the shader clock (s_memtime, core cycles) at the top of each of the eight phases of
+// the K loop's third iteration — how long each phase of the schedule really takes
+#define G8_PSTAMP(slot)                                                                                                 \
+    do { if ((p.dbg & 262144) && kt == 4 && p.park && blockIdx.x < 8 && (wave & 3) == 0 && lane == 0 && item < 24)       \
+             reinterpret_cast<long long*>(p.park)[((blockIdx.x * 2 + (wave >> 2)) * 24 + item) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define G8_STAMP(slot) do { } while (0)
+#define G8_PSTAMP(slot) do { } while (0)
 #endif
 
 // 16 MFMAs of quadrant (MH, NH): C[MH*4+mi][NH*2+nj] += A[mi][ks] * W[nj][ks]
@@ -159,6 +167,12 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     static_assert(!CV3 || ((OMODE == OUT_LINEAR || OMODE == OUT_CONVT) && TRANS == 1 && !F8), "implicit 3x3 convolution: fp16, direct epilogues");
     constexpr bool COMP = CV3 && OMODE == OUT_CONVT;    // ConvTranspose2d k2 s2 o Conv2d 3x3 composed (see launch_gemm8_deconv)
     constexpr int ESZ = F8 ? 1 : 2;                 // bytes per operand element; a tile row is 128 bytes either way
+#ifndef CVA_G8_BAL_QKV
+#define CVA_G8_BAL_QKV 1
+#endif
+    // balanced DMA schedule of the K loop (two pieces per wave and phase, see the loop): the fp16 linear / qkv launches.  The implicit-GEMM convolutions keep
+    // four pieces in phases 3, 4, 7, 8: their A stage carries a descriptor / tap set-up per call, which the split doubles (measured +2 %).
+    constexpr bool BAL = !F8 && !CV3 && (OMODE != OUT_QKV || CVA_G8_BAL_QKV);
     constexpr int KTE = 128 / ESZ;                  // K elements per tile
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -205,6 +219,20 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     if (PSHIFT && p.park && ntl >= 2 && !(p.dbg & 32768)) phi = ((((int)blockIdx.x & 7) * nk) >> 3) & ~1;
     const int nitems = ntl + (phi ? 1 : 0);
     int kcnt_next = nk;                 // K tiles of the item whose DMA is issued next (even, >= 2)
+    // Which 8-row pieces of a K tile this wave stages (four of the A tile, four of the W tile).  fp16: two pieces of EACH sub-tile the fragment reads
+    // distinguish — A sub-tile MH = rows wr*128 + MH*64 .. +64 of both wave rows, W sub-tile NH = rows wc*64 + NH*32 .. +32 of the four wave columns —
+    // i = 0, 1 in sub-tile 0, i = 2, 3 in sub-tile 1, so that every wave can issue two pieces of whichever sub-tile has just become free (the
+    // balanced DMA schedule of the K loop, BAL).  The other kernels keep 32 contiguous rows per wave.
+    auto a_piece_row = [&](int i) -> int {
+        if (!BAL) return wave * 32 + i * 8;
+        const int q = 2 * wave + (i & 1);
+        return (q >> 3) * 128 + (q & 7) * 8 + (i >> 1) * 64;
+    };
+    auto w_piece_row = [&](int i) -> int {
+        if (!BAL) return wave * 32 + i * 8;
+        const int q = 2 * wave + (i & 1);
+        return (q >> 2) * 64 + (q & 3) * 8 + (i >> 1) * 32;
+    };
     auto tile_setup = [&](int item, int& m0, int& n0, bool& swap) {
         const int fl = g8_fresh_lane();
         const int lrow = fl >> 3, lpc = fl & 7;       // (shadow the kernel-scope copies: recomputed per tile, see g8_fresh_lane)
@@ -225,13 +253,13 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             eflags = 0u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = wave * 32 + i * 8 + lrow;
-                const int lp = lpc ^ ((row >> 1) & 7);
-                const int prow = (row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3);
+                const int row = a_piece_row(i) + lrow, wrow = w_piece_row(i) + lrow;         // LDS rows of the A / W tile this lane fills
+                const int lp = lpc ^ ((row >> 1) & 7), wlp = lpc ^ ((wrow >> 1) & 7);
+                const int prow = (wrow & ~63) | (((wrow >> 2) & 3) << 4) | (((wrow >> 4) & 3) << 2) | (wrow & 3);
                 const int pp = pim + row, y = pp >> p.conv_wshift, x = pp & (p.Wd - 1);
                 eflags |= ((y == 0 ? 1u : 0u) | (y == p.H - 1 ? 2u : 0u) | (x == 0 ? 4u : 0u) | (x == p.Wd - 1 ? 8u : 0u)) << (4 * i);
                 a_voff[i] = (unsigned)(row * p.C1 * 2) + lp * 16;
-                w_voff[i] = (unsigned)((long)prow * p.ldw * 2) + lp * 16;
+                w_voff[i] = (unsigned)((long)prow * p.ldw * 2) + wlp * 16;
             }
             // input pixels: base at the top-left 3x3 tap of the tile's first pixel.  Second source (the skip connection at the
             // OUTPUT resolution, 2H x 2W): input pixel m = (b*H + y)*W + x maps to output pixel index 4*m - 2*x of parity (0, 0);
@@ -249,16 +277,16 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             cmask[0] = cmask[1] = 0u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = wave * 32 + i * 8 + lrow;
-                const int lp = lpc ^ ((row >> 1) & 7);
-                const int prow = (row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3);
+                const int row = a_piece_row(i) + lrow, wrow = w_piece_row(i) + lrow;
+                const int lp = lpc ^ ((row >> 1) & 7), wlp = lpc ^ ((wrow >> 1) & 7);
+                const int prow = (wrow & ~63) | (((wrow >> 2) & 3) << 4) | (((wrow >> 4) & 3) << 2) | (wrow & 3);
                 const int pp = pim + row, y = pp >> p.conv_wshift, x = pp & (p.Wd - 1);
                 // tap t = ky*3 + kx reads pixel (y + ky - 1, x + kx - 1): bit t set = inside the image
                 const unsigned mk = (y > 0 ? 0x1FFu : 0x1F8u) & (y < p.H - 1 ? 0x1FFu : 0x03Fu) & (x > 0 ? 0x1FFu : 0x1B6u) &
                                     (x < p.Wd - 1 ? 0x1FFu : 0x0DBu);
                 cmask[i >> 1] |= mk << ((i & 1) * 9);
                 a_voff[i] = (unsigned)(row * p.C1 * 2) + lp * 16;
-                w_voff[i] = (unsigned)((long)prow * p.ldw * 2) + lp * 16;
+                w_voff[i] = (unsigned)((long)prow * p.ldw * 2) + wlp * 16;
             }
             const long origin = ((long)m0 - p.Wd - 1) * p.C1 * 2;          // may lie before the tensor: only masked lanes would touch it
             cbase1 = (unsigned long long)(reinterpret_cast<const unsigned char*>(p.A) + origin);
@@ -272,18 +300,18 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         const long lda_b = (long)g8::opaque_s(p.lda) * ESZ, ldw_b = (long)g8::opaque_s(p.ldw) * ESZ;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = wave * 32 + i * 8 + lrow;
-            const int lp = lpc ^ ((row >> 1) & 7);
+            const int row = a_piece_row(i) + lrow, wrow = w_piece_row(i) + lrow;             // LDS rows of the A / W tile this lane fills
+            const int lp = lpc ^ ((row >> 1) & 7), wlp = lpc ^ ((wrow >> 1) & 7);
             // TRANS: LDS row wc*64 + j*16 + g*4 + r of the "W" tile holds source row wc*64 + g*16 + j*4 + r, so that a
             // lane's 16 accumulator values per output row are 16 consecutive columns (see epilogue8_direct)
-            const int prow = TRANS == 1 ? ((row & ~63) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2) | (row & 3)) : row;
+            const int prow = TRANS == 1 ? ((wrow & ~63) | (((wrow >> 2) & 3) << 4) | (((wrow >> 4) & 3) << 2) | (wrow & 3)) : wrow;
             const long ar0 = a_row(m0);
             if (!swap) {
                 a_voff[i] = (unsigned)((a_row(m0 + row) - ar0) * lda_b) + lp * 16;
-                w_voff[i] = (unsigned)((long)prow * ldw_b) + lp * 16;
+                w_voff[i] = (unsigned)((long)prow * ldw_b) + wlp * 16;
             } else {
                 a_voff[i] = (unsigned)((long)row * ldw_b) + lp * 16;
-                w_voff[i] = (unsigned)((a_row(m0 + prow) - ar0) * lda_b) + lp * 16;
+                w_voff[i] = (unsigned)((a_row(m0 + prow) - ar0) * lda_b) + wlp * 16;
             }
         }
         {
@@ -321,7 +349,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 #define G8_BDMA(voff, desc, soff, ldsaddr)                                                                   \
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(desc), \
                  "s"(soff), "s"(ldsaddr) : "memory")
-    auto stage_a_conv = [&](int buf, int kt) {
+    auto stage_a_conv = [&](int buf, int kt, int i0, int i1) {
         const int kidx = kstart + kt * kstep;
         if (COMP) {
             // K steps [0, C1/16): the composed part, K order (64-channel chunk, 2x2 input pixel) — output parity (py, px) sees input
@@ -352,9 +380,10 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             const int x0 = comp_pim & (p.Wd - 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (i < i0 || i >= i1) continue;
                 unsigned vo = a_voff[i];
                 if (!first) {         // block-uniform: the lane's pixel at the output resolution, relative to the tile's first
-                    int row = wave * 32 + i * 8 + lrow;
+                    int row = a_piece_row(i) + lrow;
                     asm volatile("" : "+v"(row));      // recomputed per K step (a few VALU ops): hoisted, the four offsets cost registers this kernel does not have
                     const int x = (comp_pim + row) & (p.Wd - 1);
                     vo = (unsigned)((4 * row - 2 * (x - x0)) * p.C2 * 2) + ((lpc ^ ((row >> 1) & 7)) << 4);
@@ -385,28 +414,31 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G8_TILE + wave * 4096);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (i < i0 || i >= i1) continue;
             const unsigned ok = (cmask[i >> 1] >> ((i & 1) * 9 + tap)) & 1u;
             const unsigned vo = ok ? a_voff[i] : 0x80000000u;
             G8_BDMA(vo, d, soff, dst + i * 1024);
         }
     };
-    auto stage_a = [&](int buf, int kt) {
-        if (CV3) { stage_a_conv(buf, kt); return; }
+    auto stage_a = [&](int buf, int kt, int i0 = 0, int i1 = 4) {      // pieces [i0, i1) of the wave's four (see a_piece_row)
+        if (CV3) { stage_a_conv(buf, kt, i0, i1); return; }
         if (F8) {      // the K tile's scale blocks first (oldest load of the stage: every counted wait that covers the tile covers them)
             const unsigned char* sbase = uniform_ptr(Sb + (long)(kstart + kt * kstep) * 1024);
             const unsigned sdst = __builtin_amdgcn_readfirstlane(lds0 + G8_SC + buf * 2048 + wave * 256);
             G8_DMA4(sc_voff, sbase, sdst);
         }
         const unsigned char* base = uniform_ptr(Ab + (long)(kstart + kt * kstep) * (G8_BK * 2));
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G8_TILE + wave * 4096);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G8_TILE + a_piece_row(0) * 128);      // pieces 1, 2, 3 at fixed distances
 #pragma unroll
-        for (int i = 0; i < 4; ++i) G8_DMA(a_voff[i], base, dst + i * 1024);
+        for (int i = 0; i < 4; ++i)
+            if (i >= i0 && i < i1) G8_DMA(a_voff[i], base, dst + (i & 1) * 1024 + (i >> 1) * (BAL ? 8192 : 2048));
     };
-    auto stage_w = [&](int buf, int kt) {
+    auto stage_w = [&](int buf, int kt, int i0 = 0, int i1 = 4) {
         const unsigned char* base = uniform_ptr(Wb + (long)(kstart + kt * kstep) * (G8_BK * 2));
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + G8_WOFF + buf * G8_TILE + wave * 4096);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + G8_WOFF + buf * G8_TILE + w_piece_row(0) * 128);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) G8_DMA(w_voff[i], base, dst + i * 1024);
+        for (int i = 0; i < 4; ++i)
+            if (i >= i0 && i < i1) G8_DMA(w_voff[i], base, dst + (i & 1) * 1024 + (i >> 1) * (BAL ? 4096 : 2048));
     };
 
     // ---- fragment read offsets: row r (r & 15 == lane & 15), logical piece ks*4 + g -> byte r*128 + ((lp ^ ((r>>1)&7)) << 4)
@@ -481,10 +513,15 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + G8_BIAS + slot * 1024);
             G8_DMA(boff, src, dst);
         }
-        stage_a(0, 0);
-        stage_w(0, 0);
-        stage_w(1, 1);
-        if (!F8) stage_a(1, 1);      // (fp8 schedule: O.A is staged in phase 1 of every iteration, the first included)
+        if (!BAL) {
+            stage_a(0, 0);
+            stage_w(0, 0);
+            stage_w(1, 1);
+            if (!F8) stage_a(1, 1);  // (fp8 schedule: O.A is staged in phase 1 of every iteration, the first included)
+        } else {                     // fp16: E whole, O without its A sub-tile 1 (phase 1 of every iteration stages that, the first included): 14 pieces
+            stage_a(0, 0, 0, 2); stage_w(0, 0, 0, 2); stage_w(0, 0, 2, 4); stage_a(0, 0, 2, 4);
+            stage_a(1, 1, 0, 2); stage_w(1, 1, 0, 2); stage_w(1, 1, 2, 4);
+        }
     };
 
     // ---- persistent loop over output tiles: the DMA of tile t+1's first two K tiles is issued BEFORE tile t's
@@ -563,6 +600,68 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
                 G8_BAR8(); G8_MMQ8(F1, FY, sA1, sWO, 1, 0); G8_BAR8();
             }
         } else {
+        if constexpr (BAL) {
+        G8_STAMP(0);
+        G8_VMCNT(6);                                // E has landed (O's six pieces may still be in flight); older epilogue stores have drained
+        G8_STAMP(1);
+        G8_BAR();
+        if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }
+        if (wr == 1) G8_BAR();                      // stagger the second wave group by one barrier
+
+        // DMA schedule (fp16): TWO pieces per wave and phase, each into the sub-tile that became free two phases earlier, each waited for four
+        // phases later — "at most the pieces of the last four phases are in flight" = vmcnt(8) — one phase before its first read:
+        //   phase  issues            (free since)   waits for (read in)        |  phase  issues            waits for (read in)
+        //   1      O.A sub 1 <- kt+1 (8)            E.A sub 1 (2)              |  5      E.A sub 1 <- kt+2  O.A sub 1 (6)
+        //   2      E.A sub 0 <- kt+2 (2)            -                          |  6      O.A sub 0 <- kt+3  -
+        //   3      E.W sub 0 <- kt+2 (2)            O.A, O.W sub 0 (4)         |  7      O.W sub 0 <- kt+3  E.A, E.W sub 0 (8)
+        //   4      E.W sub 1 <- kt+2 (3)            O.W sub 1 (5)              |  8      O.W sub 1 <- kt+3  E.W sub 1 (1)
+        // Measured before (profiles/r04_x_gemm8_phase_cycles.txt): with four pieces in each of phases 3, 4, 7, 8 those phases took 700 - 900 core cycles
+        // against 520 - 540 for the phases without DMA (2 x 256 matrix-pipe cycles): sixteen 1-KiB pieces of four waves in one slot are 256 cycles of the
+        // CU's 64-B/clk vector-memory path alone.  In the last iteration (nothing left to stage) the waits count down what is still in flight.
+        for (int kt = 0; kt < nk_it; kt += 2) {
+            const bool more = kt + 2 < nk_it;       // block-uniform
+            const bool dm = more && !no_dma;
+            // ---- phase 1
+            G8_PSTAMP(0);
+            if (!no_rd) G8_RD_W(Y, 0, 1);
+            if (!no_dma) stage_a(1, kt + 1, 2, 4);
+            G8_VMCNT(8);
+            G8_BAR(); G8_MMQ(4, A0, X, 0, 0); G8_BAR();
+            // ---- phase 2
+            G8_PSTAMP(1);
+            if (!no_rd) G8_RD_A(A1, 0, 1);
+            if (dm) stage_a(0, kt + 2, 0, 2);
+            G8_BAR(); G8_MMQ(8, A0, Y, 0, 1); G8_BAR();
+            // ---- phase 3
+            G8_PSTAMP(2);
+            if (dm) { stage_w(0, kt + 2, 0, 2); G8_VMCNT(8); } else { G8_VMCNT(4); }
+            G8_BAR(); G8_MMQ(0, A1, Y, 1, 1); G8_BAR();
+            // ---- phase 4
+            G8_PSTAMP(3);
+            if (!no_rd) { G8_RD_A(A0, 1, 0); G8_RD_W(Y, 1, 0); }
+            if (dm) { stage_w(0, kt + 2, 2, 4); G8_VMCNT(8); } else { G8_VMCNT(2); }
+            G8_BAR(); G8_MMQ(12, A1, X, 1, 0); G8_BAR();
+            // ---- phase 5
+            G8_PSTAMP(4);
+            if (!no_rd) G8_RD_W(X, 1, 1);
+            if (dm) { stage_a(0, kt + 2, 2, 4); G8_VMCNT(8); } else { G8_VMCNT(0); }
+            G8_BAR(); G8_MMQ(4, A0, Y, 0, 0); G8_BAR();
+            // ---- phase 6
+            G8_PSTAMP(5);
+            if (!no_rd) G8_RD_A(A1, 1, 1);
+            if (dm) stage_a(1, kt + 3, 0, 2);
+            G8_BAR(); G8_MMQ(8, A0, X, 0, 1); G8_BAR();
+            // ---- phase 7
+            G8_PSTAMP(6);
+            if (dm) { stage_w(1, kt + 3, 0, 2); G8_VMCNT(8); }
+            G8_BAR(); G8_MMQ(0, A1, X, 1, 1); G8_BAR();
+            // ---- phase 8
+            G8_PSTAMP(7);
+            if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }     // (after the last tile: a harmless read of stale data)
+            if (dm) { stage_w(1, kt + 3, 2, 4); G8_VMCNT(8); }
+            G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
+        }
+        } else {     // four pieces per wave in phases 3, 4, 7, 8 (the header's table): the implicit-GEMM convolutions
         G8_STAMP(0);
         G8_VMCNT(8);                                // E has landed (O may still be in flight); older epilogue stores have drained
         G8_STAMP(1);
@@ -598,6 +697,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }     // (after the last tile: a harmless read of stale data)
             if (more && !no_dma) stage_a(1, kt + 3);
             G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
+        }
         }
         }
         G8_STAMP(2);
