@@ -608,16 +608,17 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }
         if (wr == 1) G8_BAR();                      // stagger the second wave group by one barrier
 
-        // DMA schedule (fp16): TWO pieces per wave and phase, each into the sub-tile that became free two phases earlier, each waited for four
-        // phases later — "at most the pieces of the last four phases are in flight" = vmcnt(8) — one phase before its first read:
-        //   phase  issues            (free since)   waits for (read in)        |  phase  issues            waits for (read in)
-        //   1      O.A sub 1 <- kt+1 (8)            E.A sub 1 (2)              |  5      E.A sub 1 <- kt+2  O.A sub 1 (6)
-        //   2      E.A sub 0 <- kt+2 (2)            -                          |  6      O.A sub 0 <- kt+3  -
-        //   3      E.W sub 0 <- kt+2 (2)            O.A, O.W sub 0 (4)         |  7      O.W sub 0 <- kt+3  E.A, E.W sub 0 (8)
-        //   4      E.W sub 1 <- kt+2 (3)            O.W sub 1 (5)              |  8      O.W sub 1 <- kt+3  E.W sub 1 (1)
-        // Measured before (profiles/r04_x_gemm8_phase_cycles.txt): with four pieces in each of phases 3, 4, 7, 8 those phases took 700 - 900 core cycles
-        // against 520 - 540 for the phases without DMA (2 x 256 matrix-pipe cycles): sixteen 1-KiB pieces of four waves in one slot are 256 cycles of the
-        // CU's 64-B/clk vector-memory path alone.  In the last iteration (nothing left to stage) the waits count down what is still in flight.
+        // DMA schedule (fp16 linear / qkv): the sixteen pieces of a wave and iteration spread over ALL phases, 2 / 2 / 3 / 1 per half iteration (the third piece of phases
+        // 3 / 7, which read nothing, is taken from phases 4 / 8, which read twelve fragments), each into the sub-tile that became free two phases earlier, each
+        // waited for one phase before its first read — the wait counts the pieces issued since ("what the last four phases issued may be in flight"):
+        //   phase  issues                         (free since)  waits for (read in)     vmcnt |  phase  issues                         waits for (read in)      vmcnt
+        //   1      O.A sub 1 <- kt+1 (2)          (8)           E.A sub 1 (2)           8     |  5      E.A sub 1 <- kt+2 (2)          O.A sub 1 (6)            8
+        //   2      E.A sub 0 <- kt+2 (2)          (2)           -                             |  6      O.A sub 0 <- kt+3 (2)          -
+        //   3      E.W sub 0 (2), sub 1 (1)       (2, 3)        O.A, O.W sub 0 (4)      9     |  7      O.W sub 0 (2), sub 1 (1)       E.A, E.W sub 0 (8)       9
+        //   4      E.W sub 1 (1)                  (3)           O.W sub 1 (5)           8     |  8      O.W sub 1 (1)                  E.W sub 1 (1)            8
+        // Measured (profiles/r04_x_gemm8_phase_cycles.txt): with four pieces in each of phases 3, 4, 7, 8 those phases took 700 - 900 core cycles against 520 - 540 for
+        // the phases without DMA (2 x 256 matrix-pipe cycles) — sixteen 1-KiB pieces of four waves in one slot are 256 cycles of the CU's 64-B/clk vector-memory path
+        // alone; 2 / 2 / 2 / 2: 550 / 655 for phases 3 / 4; 2 / 2 / 3 / 1: 540 / 619.  In the last iteration (nothing left to stage) the waits count down what is in flight.
         for (int kt = 0; kt < nk_it; kt += 2) {
             const bool more = kt + 2 < nk_it;       // block-uniform
             const bool dm = more && !no_dma;
@@ -634,12 +635,12 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             G8_BAR(); G8_MMQ(8, A0, Y, 0, 1); G8_BAR();
             // ---- phase 3
             G8_PSTAMP(2);
-            if (dm) { stage_w(0, kt + 2, 0, 2); G8_VMCNT(8); } else { G8_VMCNT(4); }
+            if (dm) { stage_w(0, kt + 2, 0, 3); G8_VMCNT(9); } else { G8_VMCNT(4); }
             G8_BAR(); G8_MMQ(0, A1, Y, 1, 1); G8_BAR();
             // ---- phase 4
             G8_PSTAMP(3);
             if (!no_rd) { G8_RD_A(A0, 1, 0); G8_RD_W(Y, 1, 0); }
-            if (dm) { stage_w(0, kt + 2, 2, 4); G8_VMCNT(8); } else { G8_VMCNT(2); }
+            if (dm) { stage_w(0, kt + 2, 3, 4); G8_VMCNT(8); } else { G8_VMCNT(2); }
             G8_BAR(); G8_MMQ(12, A1, X, 1, 0); G8_BAR();
             // ---- phase 5
             G8_PSTAMP(4);
@@ -653,12 +654,12 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             G8_BAR(); G8_MMQ(8, A0, X, 0, 1); G8_BAR();
             // ---- phase 7
             G8_PSTAMP(6);
-            if (dm) { stage_w(1, kt + 3, 0, 2); G8_VMCNT(8); }
+            if (dm) { stage_w(1, kt + 3, 0, 3); G8_VMCNT(9); }
             G8_BAR(); G8_MMQ(0, A1, X, 1, 1); G8_BAR();
             // ---- phase 8
             G8_PSTAMP(7);
             if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }     // (after the last tile: a harmless read of stale data)
-            if (dm) { stage_w(1, kt + 3, 2, 4); G8_VMCNT(8); }
+            if (dm) { stage_w(1, kt + 3, 3, 4); G8_VMCNT(8); }
             G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
         }
         } else {     // four pieces per wave in phases 3, 4, 7, 8 (the header's table): the implicit-GEMM convolutions
