@@ -172,7 +172,10 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 #endif
     // balanced DMA schedule of the K loop (two pieces per wave and phase, see the loop): the fp16 linear / qkv launches.  The implicit-GEMM convolutions keep
     // four pieces in phases 3, 4, 7, 8: their A stage carries a descriptor / tap set-up per call, which the split doubles (measured +2 %).
-    constexpr bool BAL = !F8 && !CV3 && (OMODE != OUT_QKV || CVA_G8_BAL_QKV);
+#ifndef CVA_G8_BAL_F8
+#define CVA_G8_BAL_F8 1
+#endif
+    constexpr bool BAL = F8 ? (CVA_G8_BAL_F8 != 0) : (!CV3 && (OMODE != OUT_QKV || CVA_G8_BAL_QKV));
     constexpr int KTE = 128 / ESZ;                  // K elements per tile
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
     };
     auto stage_a = [&](int buf, int kt, int i0 = 0, int i1 = 4) {      // pieces [i0, i1) of the wave's four (see a_piece_row)
         if (CV3) { stage_a_conv(buf, kt, i0, i1); return; }
-        if (F8) {      // the K tile's scale blocks first (oldest load of the stage: every counted wait that covers the tile covers them)
+        if (F8 && !BAL) {      // the K tile's scale blocks first (oldest load of the stage: every counted wait that covers the tile covers them)
             const unsigned char* sbase = uniform_ptr(Sb + (long)(kstart + kt * kstep) * 1024);
             const unsigned sdst = __builtin_amdgcn_readfirstlane(lds0 + G8_SC + buf * 2048 + wave * 256);
             G8_DMA4(sc_voff, sbase, sdst);
@@ -432,6 +435,11 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i >= i0 && i < i1) G8_DMA(a_voff[i], base, dst + (i & 1) * 1024 + (i >> 1) * (BAL ? 8192 : 2048));
+    };
+    auto stage_sc = [&](int buf, int kt) {         // fp8, balanced schedule: the K tile's scale blocks as a piece of their own
+        const unsigned char* sbase = uniform_ptr(Sb + (long)(kstart + kt * kstep) * 1024);
+        const unsigned sdst = __builtin_amdgcn_readfirstlane(lds0 + G8_SC + buf * 2048 + wave * 256);
+        G8_DMA4(sc_voff, sbase, sdst);
     };
     auto stage_w = [&](int buf, int kt, int i0 = 0, int i1 = 4) {
         const unsigned char* base = uniform_ptr(Wb + (long)(kstart + kt * kstep) * (G8_BK * 2));
@@ -518,6 +526,9 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             stage_w(0, 0);
             stage_w(1, 1);
             if (!F8) stage_a(1, 1);  // (fp8 schedule: O.A is staged in phase 1 of every iteration, the first included)
+        } else if (F8) {             // fp8, balanced: E whole (scale blocks first), O's sub-tiles 0 — phases 1 / 2 of every iteration stage the rest of O
+            stage_sc(0, 0); stage_a(0, 0); stage_w(0, 0);
+            stage_a(1, 1, 0, 2); stage_w(1, 1, 0, 2);
         } else {                     // fp16: E whole, O without its A sub-tile 1 (phase 1 of every iteration stages that, the first included): 14 pieces
             stage_a(0, 0, 0, 2); stage_w(0, 0, 0, 2); stage_w(0, 0, 2, 4); stage_a(0, 0, 2, 4);
             stage_a(1, 1, 0, 2); stage_w(1, 1, 0, 2); stage_w(1, 1, 2, 4);
@@ -567,9 +578,55 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             //   (the prologue of an output tile stages E.A, E.W and O.W: phase 1 is the same in every iteration)
             // WAR (re-stage >= 2 phases after the last read): E.W 2 -> 4, E.A 3 -> 5, O.W 6 -> 8, O.A 7 -> 1'; the scale images
             // travel with the A stages (E: last read 3 -> 5, O: 7 -> 1').  RAW (read >= 1 phase after the retiring wait): O 4 -> 5, E 8 -> 1'.
-            G8_VMCNT(4);                            // E (tile + its scale blocks) has landed; O.W may still be in flight
+            G8_VMCNT(4);                            // E (tile + its scale blocks) has landed; four pieces of O may still be in flight
             G8_BAR8();
             if (wr == 1) G8_BAR8();                 // stagger the second wave group by one barrier
+            if constexpr (BAL) {
+            // Balanced DMA (as in the fp16 loop below, shifted by the one phase the fp8 reads are later): two pieces per wave in every phase, the scale
+            // blocks with the W sub-tile 1 pieces; waits = what has been issued since the piece that is needed:
+            //   phase  issues                              waits for (read in)                      vmcnt
+            //   1      O.W s1 + O scales <- kt+1 (3)       -
+            //   2      O.A s1 <- kt+1 (2)                  E.A s1 (3)                               9
+            //   3      E.A s0 <- kt+2 (2)                  -
+            //   4      E.W s0 <- kt+2 (2)                  O.A s0, O.W s0, O scales (5)             6
+            //   5      E.W s1 + E scales <- kt+2 (3)       -
+            //   6      E.A s1 <- kt+2 (2)                  O.A s1 (7)                               9
+            //   7      O.A s0 <- kt+3 (2)                  -
+            //   8      O.W s0 <- kt+3 (2)                  E.A s0, E.W s0, E.W s1, E scales (1', 2') 6
+            for (int kt = 0; kt < nk_it; kt += 2) {
+                const bool more = kt + 2 < nk_it;   // block-uniform
+                // ---- phase 1
+                G8F_RD_A(F0, sA0, 0, 0); G8F_RD_W(FX, 0, 0); G8F_RD_SW(sWE, 0);
+                stage_w(1, kt + 1, 2, 4); stage_sc(1, kt + 1);
+                G8_BAR8(); G8_MMQ8(F0, FX, sA0, sWE, 0, 0); G8_BAR8();
+                // ---- phase 2
+                G8F_RD_W(FY, 0, 1);
+                stage_a(1, kt + 1, 2, 4); G8_VMCNT(9);
+                G8_BAR8(); G8_MMQ8(F0, FY, sA0, sWE, 0, 1); G8_BAR8();
+                // ---- phase 3
+                G8F_RD_A(F1, sA1, 0, 1);
+                if (more) stage_a(0, kt + 2, 0, 2);
+                G8_BAR8(); G8_MMQ8(F1, FY, sA1, sWE, 1, 1); G8_BAR8();
+                // ---- phase 4
+                if (more) { stage_w(0, kt + 2, 0, 2); G8_VMCNT(6); } else { G8_VMCNT(2); }
+                G8_BAR8(); G8_MMQ8(F1, FX, sA1, sWE, 1, 0); G8_BAR8();
+                // ---- phase 5
+                G8F_RD_A(F0, sA0, 1, 0); G8F_RD_W(FY, 1, 0); G8F_RD_SW(sWO, 1);
+                if (more) { stage_w(0, kt + 2, 2, 4); stage_sc(0, kt + 2); }
+                G8_BAR8(); G8_MMQ8(F0, FY, sA0, sWO, 0, 0); G8_BAR8();
+                // ---- phase 6
+                G8F_RD_W(FX, 1, 1);
+                if (more) { stage_a(0, kt + 2, 2, 4); G8_VMCNT(9); } else { G8_VMCNT(0); }
+                G8_BAR8(); G8_MMQ8(F0, FX, sA0, sWO, 0, 1); G8_BAR8();
+                // ---- phase 7
+                G8F_RD_A(F1, sA1, 1, 1);
+                if (more) stage_a(1, kt + 3, 0, 2);
+                G8_BAR8(); G8_MMQ8(F1, FX, sA1, sWO, 1, 1); G8_BAR8();
+                // ---- phase 8
+                if (more) { stage_w(1, kt + 3, 0, 2); G8_VMCNT(6); }
+                G8_BAR8(); G8_MMQ8(F1, FY, sA1, sWO, 1, 0); G8_BAR8();
+            }
+            } else {
             for (int kt = 0; kt < nk_it; kt += 2) {
                 const bool more = kt + 2 < nk_it;   // block-uniform
                 // ---- phase 1
@@ -598,6 +655,7 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
                 // ---- phase 8
                 if (more) { stage_w(1, kt + 3); G8_VMCNT(4); }
                 G8_BAR8(); G8_MMQ8(F1, FY, sA1, sWO, 1, 0); G8_BAR8();
+            }
             }
         } else {
         if constexpr (BAL) {

@@ -27,7 +27,7 @@ def main():
     sa = torch.randint(117, 121, (M * K // 32,), device="cuda", generator=g, dtype=torch.int16).to(torch.uint8)
     sw = torch.randint(117, 121, (N * K // 32,), device="cuda", generator=g, dtype=torch.int16).to(torch.uint8)
     b = torch.zeros(N, device="cuda")
-    res = torch.randn(M, N, device="cuda") if out_kind == 1 else None
+    res = torch.randn(M, N, device="cuda", generator=g) if out_kind == 1 else None
     out = torch.empty((M, N), device="cuda", dtype=[torch.float16, torch.float32, torch.uint8][out_kind])
     osc = torch.zeros((M * N // 32,), device="cuda", dtype=torch.uint8) if out_kind == 2 else None
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
@@ -51,7 +51,9 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    print(f"mx8 M={M} N={N} K={K} out_kind={out_kind} act={act}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s"
+    import hashlib
+    dig = hashlib.sha256(first.cpu().numpy().tobytes() + (osc.cpu().numpy().tobytes() if osc is not None else b"")).hexdigest()[:16]
+    print(f"mx8 M={M} N={N} K={K} out_kind={out_kind} act={act}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s  sha {dig}"
           + (f"  RACE: {bad} mismatching elements" if bad else "  (repeat launches bit-identical)"))
 
 
