@@ -279,3 +279,42 @@ def test_the_model_sees_a_broken_schedule(monkeypatch, old, new, rule):
         return real_open(path, *a, **k)
     monkeypatch.setattr(builtins, "open", fake_open)
     assert any(b.startswith(rule) for b in _replay(False, 3))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# The counted LDS waits of the fp16 loops: G8_MMQ(n, a, b, ..) = s_waitcnt lgkmcnt(n) in front of the 16 MFMAs on register sets a, b.  LDS reads return in
+# order, so the wait retires everything but the n newest ds_reads: every read INTO a or b must be older than that.  (G8_RD_A = 8 reads, G8_RD_W = 4.)
+def _lds_waits(whole):
+    src = _strip(open(SRC).read())
+    f8 = _block(src, src.index("if constexpr (F8) {"))
+    rest = src[src.index("if constexpr (F8) {") + len(f8):]
+    bal = _block(rest, rest.index("if constexpr (BAL) {"))
+    if whole:
+        rest = rest[rest.index("if constexpr (BAL) {") + len(bal):]
+        bal = _block(rest, rest.index("else"))
+    pre = _run(bal[:bal.index("for (int kt")], {"no_rd": False, "no_dma": False})
+    loop = _run(_block(bal, bal.index("for (int kt")), {"more": True, "dm": True, "no_rd": False, "no_dma": False})
+    return pre, loop
+
+
+@pytest.mark.parametrize("whole", [False, True])
+def test_counted_lds_waits_cover_the_fragments_they_release(whole):
+    pre, loop = _lds_waits(whole)
+    seq, last = 0, {}                                   # register set -> sequence number of the newest read into it
+    checked = 0
+    for it, stmts in enumerate([pre, loop, loop, loop]):
+        for st in stmts:
+            m = re.fullmatch(r"G8_RD_(A|W)\((\w+), \d, \d\)", st)
+            if m:
+                seq += 8 if m.group(1) == "A" else 4
+                last[m.group(2)] = seq
+                continue
+            m = re.fullmatch(r"G8_MMQ\((\d+), (\w+), (\w+), \d, \d\)", st)
+            if m:
+                n = int(m.group(1))
+                for reg in (m.group(2), m.group(3)):
+                    assert reg in last, f"{reg} consumed before any read"
+                    assert seq - last[reg] >= n, f"iteration {it}: MFMAs on {reg} behind lgkmcnt({n}), but its reads are among the {n} newest"
+                assert seq - max(last[m.group(2)], last[m.group(3)]) == n, "the wait is tighter than it needs to be"
+                checked += 1
+    assert checked == 24
