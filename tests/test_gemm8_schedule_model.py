@@ -318,3 +318,48 @@ def test_counted_lds_waits_cover_the_fragments_they_release(whole):
                 assert seq - max(last[m.group(2)], last[m.group(3)]) == n, "the wait is tighter than it needs to be"
                 checked += 1
     assert checked == 24
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# Which rows a wave stages (a_piece_row / w_piece_row) and where its pieces land in LDS (one scalar base per call + immediates): evaluated from the source text.
+def _piece_rows(kind):
+    src = _strip(open(SRC).read())
+    body = _block(src, src.index(f"auto {kind}_piece_row = "))
+    plain = re.search(r"if \(!BAL\) return ([^;]+);", body).group(1)
+    q = re.search(r"const int q = ([^;]+);", body).group(1)
+    bal = re.search(r"return ([^;]+);\s*$", body.strip()).group(1)
+    imm = re.search(r"G8_DMA\(%s_voff\[i\], base, dst \+ ([^;]+)\);" % kind, src).group(1)           # e.g. (i & 1) * 1024 + (i >> 1) * (BAL ? 8192 : 2048)
+    imm = re.sub(r"\(BAL \? (\d+) : (\d+)\)", r"(\1 if BAL else \2)", imm)
+
+    def row(wave, i, BAL):
+        return eval(bal, {}, {"q": eval(q, {}, {"wave": wave, "i": i}), "i": i}) if BAL else eval(plain, {}, {"wave": wave, "i": i})
+
+    def dst_off(i, BAL):
+        return eval(imm, {}, {"i": i, "BAL": BAL})
+    return row, dst_off
+
+
+@pytest.mark.parametrize("kind,sub_rows", [("a", 64), ("w", 32)])
+@pytest.mark.parametrize("BAL", [True, False])
+def test_every_row_of_a_tile_is_staged_once_and_pieces_sit_where_the_immediates_say(kind, sub_rows, BAL):
+    row, dst_off = _piece_rows(kind)
+    covered = sorted(r for w in range(8) for i in range(4) for r in range(row(w, i, BAL), row(w, i, BAL) + 8))
+    assert covered == list(range(256))                                       # 8 waves x 4 pieces x 8 rows = the 256-row tile, no row twice
+    for w in range(8):
+        for i in range(4):
+            assert row(w, i, BAL) * 128 == row(w, 0, BAL) * 128 + dst_off(i, BAL)        # LDS address of piece i = the call's base + immediate
+            if BAL:                                                          # pieces 0, 1 in the sub-tile the fragment reads call 0, pieces 2, 3 in sub-tile 1
+                assert (row(w, i, BAL) // sub_rows) % 2 == i >> 1
+
+
+def test_halo_convolution_filter_row_permutation():
+    """conv.hip, cout_of_row: LDS row j*16 + 4g + r of the staged filter block carries the output channel that makes lane (g, li)'s 16 accumulator values of a
+    pixel two runs of 8 consecutive channels, [8g, 8g + 8) and [32 + 8g, 32 + 8g + 8) — what the direct stores and the fused head's MFMA operands rely on."""
+    src = _strip(open(os.path.join(os.path.dirname(SRC), "conv.hip")).read())
+    expr = re.search(r"int cout_of_row\(int n\) \{ return ([^;]+); \}", src).group(1)
+    cout = [eval(expr, {}, {"n": n}) for n in range(64)]
+    assert sorted(cout) == list(range(64))
+    for g in range(4):
+        for q in range(2):
+            run = [cout[(2 * q + h) * 16 + 4 * g + r] for h in range(2) for r in range(4)]       # fragments j = 2q, 2q + 1; the lane's rows 4g .. 4g + 3
+            assert run == list(range(q * 32 + g * 8, q * 32 + g * 8 + 8))
