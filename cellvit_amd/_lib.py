@@ -100,6 +100,8 @@ SYMBOLS.update({
     "cv_stitch_ring_flags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "cv_stitch_repair_rings": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "cv_write_cells_json": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int] + [C.c_void_p] * 11),
+    "cv_write_geojson": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
     "cv_stitch_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.POINTER(C.c_int32), C.c_void_p]),
 })

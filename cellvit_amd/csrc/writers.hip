@@ -134,3 +134,63 @@ extern "C" int cv_write_cells_json(const char* path, const char* header, int det
     if (!ok) { cva_set_error("cv_write_cells_json: write to %s failed", path); return CV_ERR_INVALID; }
     return CV_OK;
 }
+
+
+// The optional geojson pair (cell_detection.py:538-597 + template_geojson.py:9-52): one Feature per nucleus type present, in ascending type order
+// (`sorted(df.type.unique())`), whose geometry collects every cell of that type in slide order — MultiPolygon of the closed contour rings (cells.geojson) or
+// MultiPoint of the centroids (cell_detection.geojson).  The reference builds 10^6 Python lists and json.dump's them with indent=2; here the features' heads
+// and tails (type, uuid, properties: rendered by the caller) frame coordinates rendered from the arrays, chunks of cells on several threads as above.
+// Same document after parsing (the reference's file differs in whitespace and in its random ids anyway).
+extern "C" int cv_write_geojson(const char* path, int polygons, int n, const double* centroid, const int64_t* ct_off, const int64_t* ct_xy,
+                                const int32_t* type, int n_feat, const int32_t* feat_type, const char* const* feat_head, const char* const* feat_tail) {
+    if (!path || n < 0 || n_feat < 0 || (n && (!type || (polygons ? (!ct_off || !ct_xy) : !centroid))) || (n_feat && (!feat_type || !feat_head || !feat_tail))) {
+        cva_set_error("cv_write_geojson: bad argument"); return CV_ERR_INVALID;
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) { cva_set_error("cv_write_geojson: cannot open %s", path); return CV_ERR_INVALID; }
+    bool wrote = true;
+    auto emit = [&](const char* b, size_t len) { if (len && fwrite(b, 1, len, f) != len) wrote = false; };
+    emit("[", 1);
+    constexpr int CHUNK = 8192;
+    std::vector<int> cells;
+    for (int ft = 0; ft < n_feat && wrote; ++ft) {
+        cells.clear();
+        for (int k = 0; k < n; ++k) if (type[k] == feat_type[ft]) cells.push_back(k);
+        if (ft) emit(", ", 2);
+        emit(feat_head[ft], strlen(feat_head[ft]));
+        const int m = (int)cells.size();
+        auto render = [&](int a, int b, Out& o) {
+            for (int c = a; c < b; ++c) {
+                const int k = cells[c];
+                if (c) o.put(", ");
+                if (!polygons) { o.put("["); o.f64(centroid[2 * k]); o.put(", "); o.f64(centroid[2 * k + 1]); o.put("]"); continue; }
+                o.put("[[");
+                for (int64_t q = ct_off[k]; q < ct_off[k + 1]; ++q) {            // float(p) of integer coordinates: "123.0"
+                    o.put(q == ct_off[k] ? "[" : ", ["); o.i64(ct_xy[2 * q]); o.put(".0, "); o.i64(ct_xy[2 * q + 1]); o.put(".0]");
+                }
+                if (ct_off[k + 1] > ct_off[k]) {                                 // ring.append(ring[0])
+                    const int64_t q = ct_off[k];
+                    o.put(", ["); o.i64(ct_xy[2 * q]); o.put(".0, "); o.i64(ct_xy[2 * q + 1]); o.put(".0]");
+                }
+                o.put("]]");
+            }
+        };
+        const int nchunks = (m + CHUNK - 1) / CHUNK;
+        const int nthr = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, nchunks}));
+        std::vector<Out> outs(nthr);
+        for (int c0 = 0; c0 < nchunks && wrote; c0 += nthr) {
+            const int nc = std::min(nthr, nchunks - c0);
+            std::vector<std::thread> th;
+            for (int t = 1; t < nc; ++t)
+                th.emplace_back([&, t] { outs[t].buf.clear(); render((c0 + t) * CHUNK, std::min(m, (c0 + t + 1) * CHUNK), outs[t]); });
+            outs[0].buf.clear(); render(c0 * CHUNK, std::min(m, (c0 + 1) * CHUNK), outs[0]);
+            for (auto& x : th) x.join();
+            for (int t = 0; t < nc; ++t) emit(outs[t].buf.data(), outs[t].buf.size());
+        }
+        emit(feat_tail[ft], strlen(feat_tail[ft]));
+    }
+    emit("]", 1);
+    const bool closed = fclose(f) == 0;
+    if (!(wrote && closed)) { cva_set_error("cv_write_geojson: write to %s failed", path); return CV_ERR_INVALID; }
+    return CV_OK;
+}

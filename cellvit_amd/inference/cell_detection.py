@@ -606,11 +606,7 @@ def write_outputs(outdir: Path, wsi_metadata: dict, processed: List[str], nuclei
                         torch.from_numpy(g["contour"].astype(np.float32)), np.diff(g["ct_off"]).tolist(),
                         {"wsi_metadata": wsi_metadata, "nuclei_types": nuclei_types})
     if geojson:
-        cells_all = allc.to_dicts(patch_size, downsampling, overlap)
-        with open(outdir / "cells.geojson", "w") as f:
-            json.dump(convert_geojson(cells_all, True), f, indent=2, default=_np_default)
-        with open(outdir / "cell_detection.geojson", "w") as f:
-            json.dump(convert_geojson(cells_all, False), f, indent=2, default=_np_default)
+        write_geojson_pair(outdir, g, typ)
     th.join()
     if errors:
         raise RuntimeError(errors[0])
@@ -624,6 +620,32 @@ def _np_default(o):
     if isinstance(o, np.ndarray):
         return o.tolist()
     raise TypeError(type(o))
+
+
+def write_geojson_pair(outdir: Path, g: dict, typ: np.ndarray) -> None:
+    """cells.geojson (MultiPolygon per type) and cell_detection.geojson (MultiPoint per type) rendered from the arrays by the library's host code
+    (`cv_write_geojson`); the features' frames — type, uuid, classification name / colour — are rendered here exactly as `convert_geojson` builds them."""
+    import ctypes as C
+    import uuid
+    from .. import _lib
+    lib = _lib.load()
+    n = len(typ)
+    present = sorted(int(t) for t in np.unique(typ)) if n else []
+    ft = np.ascontiguousarray(np.asarray(present, np.int32))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    for name, polygons in (("cells.geojson", 1), ("cell_detection.geojson", 0)):
+        heads, tails = [], []
+        for t in present:
+            frame = {"type": "Feature", "id": str(uuid.uuid4()), "geometry": {"type": "MultiPolygon" if polygons else "MultiPoint", "coordinates": []},
+                     "properties": {"objectType": "annotation",
+                                    "classification": {"name": TYPE_NUCLEI_DICT.get(t, str(t)), "color": COLOR_DICT.get(t, [0, 0, 0])}}}
+            text = json.dumps(frame)
+            cut = text.index('"coordinates": [') + len('"coordinates": [')
+            heads.append(text[:cut].encode()); tails.append(text[cut:].encode())
+        H = (C.c_char_p * max(len(present), 1))(*heads)
+        T = (C.c_char_p * max(len(present), 1))(*tails)
+        _lib.check(lib.cv_write_geojson(str(outdir / name).encode(), polygons, n, p(g["centroid"]), p(g["ct_off"]), p(g["contour"]), p(typ),
+                                        len(present), p(ft), H, T))
 
 
 def convert_geojson(cell_list: List[dict], polygons: bool = False) -> List[dict]:

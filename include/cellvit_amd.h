@@ -275,6 +275,15 @@ int cv_write_cells_json(const char* path, const char* header, int detection_only
                         const double* centroid, const int64_t* ct_off, const int64_t* ct_xy, const double* type_prob,
                         const int32_t* type, const int32_t* patch_rc, const int32_t* status, const int64_t* offset_global,
                         const uint8_t* edge, const uint8_t* edge_pos);
+/* The optional geojson pair of the inference CLI (cell_segmentation/inference/cell_detection.py:538-597, `convert_geojson`, with
+ * cell_segmentation/datamodel/template_geojson.py:9-52): a JSON list of one Feature per nucleus type present, ascending type order, whose geometry
+ * collects the cells of that type in slide order — polygons != 0: MultiPolygon of the closed contour rings (ring + its first point, coordinates as
+ * floats), else MultiPoint of the centroids.  feat_type int32 [n_feat]; feat_head[i] / feat_tail[i]: the caller-rendered text around the coordinate
+ * list of feature i ('{"type": "Feature", "id": "...", "geometry": {"type": "MultiPolygon", "coordinates": [' and ']}, "properties": {...}}').
+ * Arrays as for cv_write_cells_json (centroid may be NULL for polygons, the contour arrays for points).  Same document as json.dump of the
+ * reference's list after parsing (the reference writes indent=2 and random ids).                                                      */
+int cv_write_geojson(const char* path, int polygons, int n, const double* centroid, const int64_t* ct_off, const int64_t* ct_xy,
+                     const int32_t* type, int n_feat, const int32_t* feat_type, const char* const* feat_head, const char* const* feat_tail);
 /* Cell-token pooling of the inference CLI (cell_detection.py:396-409) on the device record arrays of cv_pp_run:
  * out[rec_offset[b] + i, :] = mean over tokens_nhwc[b, floor(rmin/p):ceil(rmax/p), floor(cmin/p):ceil(cmax/p), :] for
  * record i < n_recs[b] (indices cast to uint8 as the reference does).  rec_offset: int64 [B] device (exclusive prefix

@@ -180,7 +180,7 @@ def test_to_dicts_vectorised_equals_per_cell_formulation():
 def test_native_writers_produce_the_documents_of_json_dump(tmp_path):
     """cells.json / cell_detection.json rendered by the library's host code from the arrays == json.dump of the per-cell
     dicts (same keys in the same order, same values after parsing), cells.pt == the per-cell construction of the reference
-    (cell_detection.py:438-475); the geojson pair still goes through the dicts."""
+    (cell_detection.py:438-475); the geojson pair == `convert_geojson` of the dicts (cell_detection.py:538-597) up to the random feature ids."""
     tiles = _synthetic_slide_tiles(n_cells=400)
     sc = _slide_cells_of(tiles, list(range(9)))
     sc.fr[:, 2] = np.linspace(0.1, 1.0, len(sc))                 # type_prob values that need all 17 digits
@@ -204,6 +204,13 @@ def test_native_writers_produce_the_documents_of_json_dump(tmp_path):
     assert torch.equal(g.x, allc.tokens)
     gj = json.load(open(tmp_path / "cells.geojson"))
     assert sum(len(f["geometry"]["coordinates"]) for f in gj) == len(dicts)
+    for name, polygons in (("cells.geojson", True), ("cell_detection.geojson", False)):
+        got = json.load(open(tmp_path / name))
+        want = json.loads(json.dumps(CD.convert_geojson(dicts, polygons), default=CD._np_default))
+        assert len(got) == len(want) >= 2 and all(len(f["id"]) == 36 for f in got)
+        for a, b in zip(got, want):
+            a.pop("id"); b.pop("id")
+            assert list(a.keys()) == list(b.keys()) and a == b
     # an empty slide still writes valid documents
     empty = CD.SlideCells()
     CD.write_outputs(tmp_path, meta, [], types, empty, False, 1024, 2.0, 64)
