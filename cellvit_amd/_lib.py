@@ -67,6 +67,7 @@ SYMBOLS = {
     "cv_op_attention_mx8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cv_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
+    "cv_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "cv_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "cv_op_linear": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

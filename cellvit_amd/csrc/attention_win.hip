@@ -854,7 +854,9 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
     if (BIAS) hipLaunchKernelGGL((attnw_prep_kernel<HD>), dim3(8), dim3(256), 0, stream, p.tab_h, p.tab_w, p.KH, p.KW, p.nk,
                                  reinterpret_cast<half_t*>(p.win_prep));
     static const int persistent = cva_env_int("CVA_ATTNW_P", 1);
-    if (BIAS && persistent && p.nk > (WNKB - 1) * 16 && p.S * p.heads >= 64) {
+    // (no batch term in this test: the layouts a geometry fixes — row-major V, MX-fp8 rows — are decided once for max_batch and must hold
+    //  for every smaller batch of the same geometry; with fewer items than CUs the persistent grid is simply smaller)
+    if (BIAS && persistent && p.nk > (WNKB - 1) * 16) {
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -921,7 +923,7 @@ bool attn_takes_out8(const AttnParams& p) {
     const bool bias = p.tab_h && p.tab_w;
     const bool short_seq = p.nk <= WKEYS && p.nk == p.L && p.Lp >= WKEYS &&
                            !(bias && (p.KH > 16 || p.KW > 16 || p.nk != p.KH * p.KW || !p.win_prep));
-    if (short_seq) return bias && p.nk > (WNKB - 1) * 16 && p.S * p.heads >= 64;
+    if (short_seq) return bias && p.nk > (WNKB - 1) * 16;       // batch-independent (see launch_attnw_impl)
     if (!bias) return true;
     return (p.KW == 64 && p.KH <= 64 && p.nk == p.KH * p.KW) || p.KH + p.KW <= 64;
 }
@@ -934,7 +936,7 @@ bool attn_takes_vrm(const AttnParams& p, size_t elem_size) {
     // would launch_attention_win take this layer (short key sequences, window OR global)?  Then only its persistent kernel reads row-major V
     const bool short_seq = p.nk <= WKEYS && p.nk == p.L && p.Lp >= WKEYS &&
                            !(bias && (p.KH > 16 || p.KW > 16 || p.nk != p.KH * p.KW || !p.win_prep));
-    if (short_seq) return bias && p.nk > (WNKB - 1) * 16 && p.S * p.heads >= 64;
+    if (short_seq) return bias && p.nk > (WNKB - 1) * 16;       // batch-independent (see launch_attnw_impl)
     // Everything else runs attn2_kernel, whose row-major form (ablation builds) is SLOWER: 10.06 against
     // 9.19 ms per global SAM-H launch of 64 tiles (profiles/r04_d_vrm_kernels.txt: two ds_read_b64_tr_b16 per fragment instead of one
     // ds_read2_b64), while the qkv projection of a global layer already writes V^T with 16-byte stores.  Global layers keep V^T.

@@ -125,6 +125,7 @@ struct cv_handle {
     cv_config cfg{};
     bool finalized = false;
     int debug = 0;
+    int opt_fp8_proj = 1;     // cv_set_option("fp8_proj"): 0 keeps attn.proj on fp16 on the fp8 engine
     std::map<std::string, HostTensor> raw;
     std::vector<void*> allocs;        // weights
     std::vector<void*> ws_allocs;     // workspace (geometry dependent)
@@ -1126,7 +1127,7 @@ extern "C" int cv_set_geometry(cv_handle* h, int max_batch, int H, int W) {
             bool any_win = false, any_glob = false, packed = true;
             for (auto& b : h->blocks) { if (b.global) any_glob = true; else any_win = true; packed = packed && b.proj8.W8; }
             static const int no_p8 = cva_env_int("CVA_NO_PROJ8", 0);      // ablation builds: fp16 proj on the fp8 engine (A/B)
-            g.proj8 = (!no_p8 && packed && (!any_win || attn_takes_out8(aw)) && (!any_glob || attn_takes_out8(ag))) ? 1 : 0;
+            g.proj8 = (!no_p8 && h->opt_fp8_proj && packed && (!any_win || attn_takes_out8(aw)) && (!any_glob || attn_takes_out8(ag))) ? 1 : 0;
             if (g.proj8) {
                 const size_t K8 = (size_t)96 * heads;
                 CVA_TRY(A(&h->attn8, M * K8, true));             // (the 16 pad columns of every head stay zero)
@@ -1251,6 +1252,14 @@ extern "C" int cv_forward_u8(cv_handle* h, const uint8_t* x_u8, const float* mea
 extern "C" int cv_geometry_flags(const cv_handle* h) {
     if (!h || !h->g.set) return 0;
     return (h->g.v_rm ? 1 : 0) | (h->g.proj8 ? 2 : 0);
+}
+
+extern "C" int cv_set_option(cv_handle* h, const char* name, int value) {
+    if (!h || !name) return CV_ERR_INVALID;
+    if (h->g.set) { cva_set_error("cv_set_option must precede cv_set_geometry"); return CV_ERR_STATE; }
+    if (!strcmp(name, "fp8_proj")) { h->opt_fp8_proj = value ? 1 : 0; return CV_OK; }
+    cva_set_error("cv_set_option: unknown option '%s'", name);
+    return CV_ERR_INVALID;
 }
 
 extern "C" int cv_set_debug(cv_handle* h, int enable) {

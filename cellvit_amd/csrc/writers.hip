@@ -53,6 +53,29 @@ const int8_t EDGE_TABLE[16][7] = {   // n, then up to 3 (dr, dc) pairs; index = 
     {-1}, {1, 0, -1}, {1, 1, 0}, {3, 1, 0, 1, -1, 0, -1}, {1, 0, 1}, {-1}, {3, 0, 1, 1, 1, 1, 0}, {-1},
     {1, -1, 0}, {3, 0, -1, -1, -1, -1, 0}, {-1}, {-1}, {3, -1, 0, -1, 1, 0, 1}, {-1}, {-1}, {-1}};
 
+// One round of chunk rendering: chunks [c0, c0 + nc) on up to nc threads, each into its own buffer.  Nothing may throw through the
+// extern "C" entry points (ctypes callers would be terminated): thread exhaustion (std::system_error) falls back to rendering the
+// remaining chunks on the calling thread, every started thread is joined, and allocation failures inside a chunk (std::bad_alloc from
+// the buffers) are caught per chunk and reported.
+template <class Render>
+bool render_round(int nc, std::vector<Out>& outs, Render&& render_chunk) {
+    std::vector<std::thread> th;
+    std::vector<char> failed((size_t)nc, 0);
+    auto guarded = [&](int t) {
+        try { outs[t].buf.clear(); render_chunk(t, outs[t]); } catch (...) { failed[t] = 1; }
+    };
+    int started = 1;                                   // chunk 0 runs on the calling thread
+    try {
+        th.reserve((size_t)nc);
+        for (int t = 1; t < nc; ++t) { th.emplace_back(guarded, t); started = t + 1; }
+    } catch (...) { /* no more threads: the rest is rendered here */ }
+    guarded(0);
+    for (int t = started; t < nc; ++t) guarded(t);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < nc; ++t) if (failed[t]) return false;
+    return true;
+}
+
 }  // namespace
 
 extern "C" int cv_write_cells_json(const char* path, const char* header, int detection_only, int n, const int64_t* bbox,
@@ -116,21 +139,20 @@ extern "C" int cv_write_cells_json(const char* path, const char* header, int det
     constexpr int CHUNK = 8192;
     const int nchunks = (n + CHUNK - 1) / CHUNK;
     const int nthr = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, nchunks}));
-    std::vector<Out> outs(nthr);
-    for (int c0 = 0; c0 < nchunks && wrote; c0 += nthr) {
-        const int nc = std::min(nthr, nchunks - c0);
-        std::vector<std::thread> th;
-        for (int t = 1; t < nc; ++t)
-            th.emplace_back([&, t] { outs[t].buf.clear(); render((c0 + t) * CHUNK, std::min(n, (c0 + t + 1) * CHUNK), outs[t]); });
-        outs[0].buf.clear(); render(c0 * CHUNK, std::min(n, (c0 + 1) * CHUNK), outs[0]);
-        for (auto& x : th) x.join();
-        for (int t = 0; t < nc; ++t) emit(outs[t].buf);
-    }
-    Out o;
-    o.put(n ? "\n]}" : "]}");
-    emit(o.buf);
-    const bool closed = fclose(f) == 0;          // always closed, also after a failed write
-    const bool ok = wrote && closed;
+    bool rendered = true;
+    try {
+        std::vector<Out> outs(nthr);
+        for (int c0 = 0; c0 < nchunks && wrote && rendered; c0 += nthr) {
+            const int nc = std::min(nthr, nchunks - c0);
+            rendered = render_round(nc, outs, [&](int t, Out& o) { render((c0 + t) * CHUNK, std::min(n, (c0 + t + 1) * CHUNK), o); });
+            for (int t = 0; t < nc && rendered; ++t) emit(outs[t].buf);
+        }
+        Out o;
+        o.put(n ? "\n]}" : "]}");
+        emit(o.buf);
+    } catch (...) { rendered = false; }
+    const bool closed = fclose(f) == 0;          // always closed, also after a failed write / a failed allocation
+    const bool ok = wrote && closed && rendered;
     if (!ok) { cva_set_error("cv_write_cells_json: write to %s failed", path); return CV_ERR_INVALID; }
     return CV_OK;
 }
@@ -148,12 +170,13 @@ extern "C" int cv_write_geojson(const char* path, int polygons, int n, const dou
     }
     FILE* f = fopen(path, "wb");
     if (!f) { cva_set_error("cv_write_geojson: cannot open %s", path); return CV_ERR_INVALID; }
-    bool wrote = true;
+    bool wrote = true, rendered = true;
     auto emit = [&](const char* b, size_t len) { if (len && fwrite(b, 1, len, f) != len) wrote = false; };
     emit("[", 1);
     constexpr int CHUNK = 8192;
+    try {
     std::vector<int> cells;
-    for (int ft = 0; ft < n_feat && wrote; ++ft) {
+    for (int ft = 0; ft < n_feat && wrote && rendered; ++ft) {
         cells.clear();
         for (int k = 0; k < n; ++k) if (type[k] == feat_type[ft]) cells.push_back(k);
         if (ft) emit(", ", 2);
@@ -165,12 +188,12 @@ extern "C" int cv_write_geojson(const char* path, int polygons, int n, const dou
                 if (c) o.put(", ");
                 if (!polygons) { o.put("["); o.f64(centroid[2 * k]); o.put(", "); o.f64(centroid[2 * k + 1]); o.put("]"); continue; }
                 o.put("[[");
-                for (int64_t q = ct_off[k]; q < ct_off[k + 1]; ++q) {            // float(p) of integer coordinates: "123.0"
-                    o.put(q == ct_off[k] ? "[" : ", ["); o.i64(ct_xy[2 * q]); o.put(".0, "); o.i64(ct_xy[2 * q + 1]); o.put(".0]");
+                for (int64_t q = ct_off[k]; q < ct_off[k + 1]; ++q) {            // the integer contour lists as they are (cell_detection.py:358-363, 564-568)
+                    o.put(q == ct_off[k] ? "[" : ", ["); o.i64(ct_xy[2 * q]); o.put(", "); o.i64(ct_xy[2 * q + 1]); o.put("]");
                 }
-                if (ct_off[k + 1] > ct_off[k]) {                                 // ring.append(ring[0])
+                if (ct_off[k + 1] > ct_off[k]) {                                 // c.append(c[0])
                     const int64_t q = ct_off[k];
-                    o.put(", ["); o.i64(ct_xy[2 * q]); o.put(".0, "); o.i64(ct_xy[2 * q + 1]); o.put(".0]");
+                    o.put(", ["); o.i64(ct_xy[2 * q]); o.put(", "); o.i64(ct_xy[2 * q + 1]); o.put("]");
                 }
                 o.put("]]");
             }
@@ -178,19 +201,16 @@ extern "C" int cv_write_geojson(const char* path, int polygons, int n, const dou
         const int nchunks = (m + CHUNK - 1) / CHUNK;
         const int nthr = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, nchunks}));
         std::vector<Out> outs(nthr);
-        for (int c0 = 0; c0 < nchunks && wrote; c0 += nthr) {
+        for (int c0 = 0; c0 < nchunks && wrote && rendered; c0 += nthr) {
             const int nc = std::min(nthr, nchunks - c0);
-            std::vector<std::thread> th;
-            for (int t = 1; t < nc; ++t)
-                th.emplace_back([&, t] { outs[t].buf.clear(); render((c0 + t) * CHUNK, std::min(m, (c0 + t + 1) * CHUNK), outs[t]); });
-            outs[0].buf.clear(); render(c0 * CHUNK, std::min(m, (c0 + 1) * CHUNK), outs[0]);
-            for (auto& x : th) x.join();
-            for (int t = 0; t < nc; ++t) emit(outs[t].buf.data(), outs[t].buf.size());
+            rendered = render_round(nc, outs, [&](int t, Out& o) { render((c0 + t) * CHUNK, std::min(m, (c0 + t + 1) * CHUNK), o); });
+            for (int t = 0; t < nc && rendered; ++t) emit(outs[t].buf.data(), outs[t].buf.size());
         }
         emit(feat_tail[ft], strlen(feat_tail[ft]));
     }
+    } catch (...) { rendered = false; }
     emit("]", 1);
     const bool closed = fclose(f) == 0;
-    if (!(wrote && closed)) { cva_set_error("cv_write_geojson: write to %s failed", path); return CV_ERR_INVALID; }
+    if (!(wrote && closed && rendered)) { cva_set_error("cv_write_geojson: write to %s failed", path); return CV_ERR_INVALID; }
     return CV_OK;
 }

@@ -653,7 +653,7 @@ def convert_geojson(cell_list: List[dict], polygons: bool = False) -> List[dict]
     by_type: Dict[int, list] = defaultdict(list)
     for c in cell_list:
         if polygons:
-            ring = [list(map(float, p)) for p in c["contour"]]
+            ring = [list(p) for p in c["contour"]]            # the integer contour lists as they are (:564-568: `c.append(c[0])`)
             ring.append(ring[0])
             by_type[c["type"]].append([ring])
         else:

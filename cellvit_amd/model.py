@@ -68,7 +68,8 @@ def _build_tree(root: nn.Module, cfg: CellViTConfig) -> None:
 class _Engine:
     """One finalized C handle (weights packed for one compute dtype) + its geometry cache."""
 
-    def __init__(self, cfg: CellViTConfig, dtype: int, state: "OrderedDict[str, torch.Tensor]", debug: bool):
+    def __init__(self, cfg: CellViTConfig, dtype: int, state: "OrderedDict[str, torch.Tensor]", debug: bool,
+                 options: Optional[Dict[str, int]] = None):
         self.lib = _lib.load()
         self.cfg = cfg
         self.dtype = dtype
@@ -92,6 +93,8 @@ class _Engine:
         try:
             if debug:
                 _lib.check(self.lib.cv_set_debug(self.h, 1))
+            for name, value in (options or {}).items():
+                _lib.check(self.lib.cv_set_option(self.h, name.encode(), int(value)))
             for key, t in state.items():
                 a = t.detach().to("cpu")
                 if a.dtype == torch.long:
@@ -192,9 +195,11 @@ class CellViT(nn.Module):
         nb, nh, nt = _cfg.branch_out
         self.branches_output = {"nuclei_binary_map": nb, "hv_map": nh, "nuclei_type_maps": nt}
         self.compute_dtype = compute_dtype
+        # fp8 engine only: False keeps attn.proj on fp16 (qkv / fc1 / fc2 on MX-fp8; the tighter accuracy bounds of DESIGN §4) — cv_set_option
+        self.fp8_proj = True
         self.debug_taps = False
         _build_tree(self, _cfg)
-        self._engines: Dict[Tuple[int, int], _Engine] = {}     # (device index, compute dtype) -> packed weights + workspace
+        self._engines: Dict[Tuple[int, int, int], _Engine] = {}     # (device index, compute dtype, options) -> packed weights + workspace
         self._last_argmax = None
         self._last_maps = None
         self.eval()
@@ -236,10 +241,11 @@ class CellViT(nn.Module):
     def _engine(self, dtype: int, device: torch.device) -> _Engine:
         """One handle per (device, dtype): weights and workspace live on the device that was current at creation."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        e = self._engines.get((idx, dtype))
+        opt = int(bool(self.fp8_proj)) if dtype == _lib.DTYPE_F8 else 1
+        e = self._engines.get((idx, dtype, opt))
         if e is None:
-            e = _Engine(self.cfg, dtype, self.state_dict(), self.debug_taps)
-            self._engines[(idx, dtype)] = e
+            e = _Engine(self.cfg, dtype, self.state_dict(), self.debug_taps, {"fp8_proj": opt} if dtype == _lib.DTYPE_F8 else None)
+            self._engines[(idx, dtype, opt)] = e
         return e
 
     def engine_flags(self) -> int:

@@ -64,6 +64,15 @@ def cellvit256_config(num_nuclei_classes=6, num_tissue_classes=19, regression_lo
                          pos_grid=14, name="CellViT256")
 
 
+def cellvit_generic_config(num_nuclei_classes, num_tissue_classes, embed_dim, depth, num_heads, extract_layers,
+                           mlp_ratio=4, regression_loss=False):
+    """The generic class ``CellViT(...)`` (cellvit.py:57-75): a ViT with cls token, pos-embed grid 14 (utils.py:93)."""
+    return CellViTConfig(arch=ARCH_VIT, embed_dim=embed_dim, depth=depth, num_heads=num_heads,
+                         extract_layers=tuple(extract_layers), num_nuclei_classes=num_nuclei_classes,
+                         num_tissue_classes=num_tissue_classes, mlp_ratio=int(mlp_ratio),
+                         regression_loss=regression_loss, pos_grid=14, name="CellViT")
+
+
 _SAM = {  # cellvit.py:646-665
     "SAM-B": dict(embed_dim=768, depth=12, num_heads=12, global_attn_indexes=(2, 5, 8, 11),
                   extract_layers=(3, 6, 9, 12)),

@@ -125,6 +125,11 @@ int cv_set_debug(cv_handle* h, int enable);
 /* Engine choices of the current geometry (0 before cv_set_geometry): bit 0 = the window blocks keep V row-major (qkv epilogue + window
  * attention kernel with the transposing LDS read), bit 1 = fp8 engine with proj on MX-fp8 (the attention kernels emit MX-fp8 rows).   */
 int cv_geometry_flags(const cv_handle* h);
+/* Run-time engine options (production builds; must precede cv_set_geometry — a later call returns CV_ERR_STATE):
+ *   "fp8_proj" = 0 : the fp8 engine keeps attn.proj on fp16 (qkv / fc1 / fc2 on MX-fp8 only: the tighter accuracy bounds of
+ *                    tests/test_gpu_fp8.py's second leg); 1 (default): proj on MX-fp8 as well where the geometry allows it.
+ * No counterpart in the reference (its only reduced precision is torch.autocast fp16, cell_detection.py:314-316).            */
+int cv_set_option(cv_handle* h, const char* name, int value);
 int cv_debug_read(cv_handle* h, const char* name, float* host_dst, size_t capacity, size_t* n_out);
 
 /* Live per-kernel-class timing (HIP events recorded on the launch stream around every launch of the

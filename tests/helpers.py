@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-from cellvit_amd.spec import cellvit256_config, cellvit_sam_config
+from cellvit_amd.spec import cellvit256_config, cellvit_generic_config, cellvit_sam_config
 from cellvit_amd.weights import make_state_dict, normalize_tile, synthetic_tile_u8
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -21,6 +21,8 @@ CASES = {
     "samb_nohead_64": (lambda: cellvit_sam_config("SAM-B", 6, 0), 2, 64, 64),
     "vit256_reg_64": (lambda: cellvit256_config(6, 19, True), 2, 64, 64),    # regression_loss=True (cellvit.py:191-196)
     "samb_reg_64": (lambda: cellvit_sam_config("SAM-B", 6, 19, True), 2, 64, 64),
+    "vitgen768_64": (lambda: cellvit_generic_config(6, 19, 768, 12, 12, (3, 6, 9, 12)), 2, 64, 64),   # generic CellViT(...), cellvit.py:57-75
+    "saml_64": (lambda: cellvit_sam_config("SAM-L"), 2, 64, 64),                                       # CellViTSAM(..., "SAM-L"), cellvit.py:653-658
 }
 
 

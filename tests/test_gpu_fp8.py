@@ -306,6 +306,40 @@ def test_forward_fp8_error_statistics(name):
     assert s8["nuclei_binary_map_argmax"] >= 0.96 and s8["nuclei_type_map_argmax"] >= 0.945, s8
 
 
+@pytest.mark.parametrize("name", ["samh_256", "samh_1024"])
+def test_forward_fp8_with_fp16_proj_keeps_the_round3_bounds(name):
+    """`model.fp8_proj = False` (cv_set_option "fp8_proj" = 0, a run-time switch of the PRODUCTION library): attn.proj stays on fp16,
+    qkv / fc1 / fc2 on MX-fp8 — the round-3 engine with its round-3 bounds: mean-abs < 0.03, argmax agreement >= 0.97 / 0.95."""
+    cfg, sd, x, gold = load_case(name)
+    m = _model(cfg, sd, "fp8")
+    m.fp8_proj = False
+    out = m(x.cuda(), retrieve_tokens=True)
+    torch.cuda.synchronize()
+    assert not (m.engine_flags() & 2), m.engine_flags()
+    st = {}
+    for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
+        a = out[k].float().cpu().numpy()
+        if k in gold:
+            gk, ak = gold[k], a
+        else:
+            c = gold[k + "_center"].shape[-1]
+            H = a.shape[-1]
+            y0 = (H - c) // 2
+            gk = np.concatenate([gold[k + "_center"], gold[k + "_corner"]], 0)
+            ak = np.concatenate([a[..., y0:y0 + c, y0:y0 + c], a[..., :c, :c]], 0)
+        st[k] = (float(np.abs(ak - gk).max()), float(np.abs(ak - gk).mean()))
+        if k != "hv_map":
+            st[k + "_argmax"] = float((ak.argmax(1) == gk.argmax(1)).mean())
+    print(f"\n[{name}] fp8 engine, proj on fp16: {st}")
+    for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
+        assert st[k][0] < 0.25 and st[k][1] < 0.03, (k, st[k])
+    assert st["nuclei_binary_map_argmax"] >= 0.97 and st["nuclei_type_map_argmax"] >= 0.95, st
+    # the option cannot change under a live geometry: a second engine is built instead (model keys its engines by the option)
+    m.fp8_proj = True
+    m(x.cuda())
+    assert m.engine_flags() & 2
+
+
 def test_samh_1024_fp8_instance_level_gate():
     """Instance-level gate for the fp8 engine (SURVEY §8 row "HV/type logits": tolerance gates at the level the product is consumed).
     Random-weight logits hold no nuclei (the golden tile post-processes to 0-3 instances), so the gate is built from the engine's REAL

@@ -63,7 +63,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     cv = ref_import.import_cellvit()
     which = sys.argv[1:] or ["vit256_256", "vit256_b2_128x192", "samb_128", "samh_256", "samh_1024", "vit256_1024",
-                             "vit256_nohead_64", "samb_nohead_64", "vit256_reg_64", "samb_reg_64"]
+                             "vit256_nohead_64", "samb_nohead_64", "vit256_reg_64", "samb_reg_64", "vitgen768_64", "saml_64"]
     if "vit256_256" in which:   # BASELINE.json configs[0]
         run("vit256_256", cv.CellViT256(None, 6, 19), cellvit256_config(), 1, 256, 256)
     if "vit256_b2_128x192" in which:   # batch > 1, non-square (bicubic pos-embed w/h handling)
@@ -85,6 +85,11 @@ def main():
         run("vit256_reg_64", cv.CellViT256(None, 6, 19, regression_loss=True), cellvit256_config(6, 19, True), 2, 64, 64)
     if "samb_reg_64" in which:        # the same through CellViTSAM.forward (cellvit.py:623-630)
         run("samb_reg_64", cv.CellViTSAM(None, 6, 19, "SAM-B", regression_loss=True), cellvit_sam_config("SAM-B", 6, 19, True), 2, 64, 64)
+    if "vitgen768_64" in which:       # the generic class CellViT(...) (cellvit.py:57-75; arch "CellViT" of cell_detection.py:173-190) with non-preset dims:
+        from cellvit_amd.spec import cellvit_generic_config   # ViT-B/16 geometry: D 768, 12 heads (hd 64), skip dims 512 / 256, bottleneck 512
+        run("vitgen768_64", cv.CellViT(6, 19, 768, 3, 12, 12, [3, 6, 9, 12]), cellvit_generic_config(6, 19, 768, 12, 12, (3, 6, 9, 12)), 2, 64, 64)
+    if "saml_64" in which:            # CellViTSAM(..., "SAM-L") (cellvit.py:653-658): D 1024, depth 24, hd 64, global blocks 5 / 11 / 17 / 23
+        run("saml_64", cv.CellViTSAM(None, 6, 19, "SAM-L"), cellvit_sam_config("SAM-L"), 2, 64, 64)
 
 
 if __name__ == "__main__":
