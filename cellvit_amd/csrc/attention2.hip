@@ -18,6 +18,18 @@
 //          S^T MFMA against a per-tile one-hot matrix E[key][kh | KH+kw] — no per-element lookups.
 //   BIAS 2 (KW == 64 == key tile: 1024-px tiles, global blocks): kh is constant per key tile (one LDS
 //          scalar per query and tile), the kw term is tile-invariant and lives in registers.
+//
+// Round 5 — the softmax's arithmetic moved INTO the contraction (the kernel is VALU-issue bound: 6 vector instructions per score next to
+// 44 MFMAs per wave and key tile, profiles/r03_s_kernel_insts.txt):
+//   * Q is pre-scaled by scale * log2(e) when its fragments are loaded (the reference rounds q * scale to fp16 as well,
+//     image_encoder.py:244 under autocast), the rel-pos tables' products follow (relcat holds bias * log2 e): S^T leaves the MFMAs in
+//     the log2 domain — no per-score multiply;
+//   * the accumulators of S^T are not zeroed but INITIALISED with what used to be added per score afterwards: the tile-invariant kw
+//     bias (BIAS 2) and the per-tile shift  bh(kt) - m_ref  (the kh bias of the tile minus the lazy reference maximum);
+//   * fp16, hd 80 (SAM-H, the production case): the shift does not even cost the initialising add — the head dim is zero-padded from
+//     80 to 96 contraction slots, slots 80 / 81 carry  1.0  on the K side (set once in the LDS tile's pad columns) and the shift as an
+//     fp16 hi + lo pair on the Q side (patched per tile: 2 conversions per query block), so C = the kw registers as they are.
+// Per score that leaves: maximum (v_max3), exp2, row-sum add, half a conversion.
 #include "attention.h"
 
 #include <type_traits>
@@ -100,12 +112,15 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     const T* __restrict__ Kg = reinterpret_cast<const T*>(p.K) + (long)sh * p.L * HD;
     const T* __restrict__ Vg = reinterpret_cast<const T*>(p.Vt) + (VRM ? (long)sh * p.L * HD : (long)sh * HD * p.Lp);
 
+    // SLOT: the per-tile softmax shift rides in contraction slots HD, HD + 1 of the zero-padded head dim (see the header)
+    constexpr bool SLOT = sizeof(T) == 2 && HD == 80 && BIAS == 2;
     if (HDP > HD) {
         for (int i = tid; i < KT * (HDP - HD); i += NT) {
             const int r = i / (HDP - HD), c = i - r * (HDP - HD);
-            Ks[r * PK + HD + c] = TR::from_float(0.f);
+            Ks[r * PK + HD + c] = TR::from_float((SLOT && c < 2) ? 1.f : 0.f);
         }
     }
+    const float c1 = p.scale * LOG2E;                  // Q is pre-scaled by it: scores and rel-pos terms come out of the MFMAs in the log2 domain
 
     // ---- Q fragments (B operand of S^T): lane -> query li of block qb, head-dim slice g*8.. ----
     Frag qf[2][NKS];
@@ -116,6 +131,8 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
         for (int ks = 0; ks < NKS; ++ks) {
             const int d0 = ks * 32 + g * 8;
             qf[qb][ks] = (row < p.L && d0 < HD) ? TR::load_frag(Qg + (long)row * HD + d0) : TR::zero_frag();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) set_frag<T>(qf[qb][ks], j, TR::to_float(qf[qb][ks].v[j]) * c1);
         }
     }
 
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     }
     __syncthreads();
 
-    const float c1 = p.scale * LOG2E;                  // relcat holds bias / scale, so bias * log2e = relcat * c1
+    // (relcat = (Q c1) . tab / scale = bias * log2 e: no further factor)
     // BIAS 1: Q-side bias fragments (rows of relcat);  BIAS 2: tile-invariant kw terms in registers
     Frag bf[2][NBK];
     float bw[2][4][4];
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    bw[qb][kb][r] = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + p.KH + kb * 16 + g * 4 + r]) * c1;
+                    bw[qb][kb][r] = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + p.KH + kb * 16 + g * 4 + r]);
     }
 
     f32x4 o[2][ND];
@@ -278,7 +295,9 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int n = 0; n < ND; ++n) o[qb][n] = (f32x4)(0.f);
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    // m_run: the lazy reference maximum (log2 domain).  It starts at 0 and the FIRST tile always takes the update path below, which then
+    // sets it to the tile's row maximum (the accumulators are still zero: any finite factor is harmless)
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
 
     const bool wave_active = q0 < p.L;                 // waves whose 32 queries are all padding only help staging
 
@@ -329,12 +348,39 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
         if (!wave_active) return;
         const int nkb = LAST ? min(4, (p.nk - kt * KT + 15) / 16) : 4;      // key blocks of this tile that hold real keys
 
-        // ---- S^T blocks: s[qb][kb][r] = score(query li of qb, key kb*16 + g*4 + r) / scale ----
+        // ---- S^T blocks: s[qb][kb][r] = log2-domain exponent of (query li of qb, key kb*16 + g*4 + r) RELATIVE to the lazy reference
+        // maximum:  (q c1) . k  +  kw bias  +  kh bias of the tile  -  m_run.   Everything but the dot product is the accumulators'
+        // initial value (or, SLOT, two contraction slots of the padded head dim) — see the header.
         // (k-step outermost: the 8 MFMAs of a k-step write 8 different accumulators, so dependent MFMAs are 8 apart
         //  instead of 2 — the matrix pipe does not stall on its own result)
+        float shift[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float bh = 0.f;
+            if (BIAS == 2) bh = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + kt]);   // kh == kt
+            shift[qb] = bh - m_run[qb];
+            if constexpr (SLOT) {      // slots 80 / 81 = elements 0 / 1 of the last k-step's fragment on the lanes with g == 2
+                const half_t hi = (half_t)shift[qb];
+                const half_t lo = (half_t)(shift[qb] - (float)hi);
+                qf[qb][NKS - 1].v[0] = g == 2 ? hi : qf[qb][NKS - 1].v[0];
+                qf[qb][NKS - 1].v[1] = g == 2 ? lo : qf[qb][NKS - 1].v[1];
+            }
+        }
         f32x4 s[2][4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) { s[0][kb] = (f32x4)(0.f); s[1][kb] = (f32x4)(0.f); }
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                if constexpr (SLOT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[qb][kb][r] = bw[qb][kb][r];
+                } else if (BIAS == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[qb][kb][r] = bw[qb][kb][r] + shift[qb];
+                } else {
+                    s[qb][kb] = (f32x4)(shift[qb]);
+                }
+            }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
@@ -358,56 +404,62 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
             }
         }
         // ---- online softmax per query, LAZY reference maximum (log2 domain) ----
-        //   t = s * (scale*log2e) [+ kw bias];  p = 2^(t + bh - m_ref)
-        // m_ref is only raised when some score of the tile exceeds it by more than LAZY_TAU (checked wave-wide with one
-        // ballot); otherwise the tile needs NO cross-lane reduction and NO rescale of the output accumulators — p may then
-        // be as large as 2^LAZY_TAU, harmless in fp16/fp32.  The row sum is kept as a per-lane partial (the four lanes
-        // of a query are combined once, after the key loop).  Mathematically identical to the eager form.
+        //   p = 2^t,  t = the accumulator (exponent relative to m_run).
+        // m_run is only raised when some t of the tile exceeds LAZY_TAU (checked wave-wide with one ballot; always on the first tile,
+        // which sets it); otherwise the tile needs NO cross-lane reduction and NO rescale of the output accumulators — p may then be as
+        // large as 2^LAZY_TAU, harmless in fp16/fp32.  The row sum is kept as a per-lane partial (the four lanes of a query are combined
+        // once, after the key loop).  Mathematically identical to the eager form.
         constexpr float LAZY_TAU = 8.0f;
         const bool ragged = LAST && (p.nk & (KT - 1)) != 0;                   // only the last tile can hold invalid keys
         Frag pf[2][2];
-        float tmax[2], bh[2];
+        float tmax[2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            bh[qb] = 0.f;
-            if (BIAS == 2) bh[qb] = TR::to_float(Rc[(wave * QW + qb * 16 + li) * RC2 + kt]) * c1;   // kh == kt
-            float mx = -INFINITY;
+            if (LAST && ragged) {
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = BIAS == 2 ? fmaf(s[qb][kb][r], c1, bw[qb][kb][r]) : s[qb][kb][r] * c1;
-                    if (LAST && ragged) { const int key = kt * KT + kb * 16 + g * 4 + r; v = key < p.nk ? v : -INFINITY; }
-                    s[qb][kb][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            tmax[qb] = mx + bh[qb];
+                    for (int r = 0; r < 4; ++r) { const int key = kt * KT + kb * 16 + g * 4 + r; s[qb][kb][r] = key < p.nk ? s[qb][kb][r] : -INFINITY; }
+            }
+            float mx = __builtin_fmaxf(__builtin_fmaxf(s[qb][0][0], s[qb][0][1]), s[qb][0][2]);      // (nested pairs: v_max3_f32)
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][0][3]), s[qb][1][0]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][1][1]), s[qb][1][2]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][1][3]), s[qb][2][0]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][2][1]), s[qb][2][2]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][2][3]), s[qb][3][0]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][3][1]), s[qb][3][2]);
+            tmax[qb] = __builtin_fmaxf(mx, s[qb][3][3]);
         }
-        if (__any((tmax[0] > m_run[0] + LAZY_TAU) || (tmax[1] > m_run[1] + LAZY_TAU))) {      // wave-uniform, rare after the first tiles
+        if (kt == 0 || __any((tmax[0] > LAZY_TAU) || (tmax[1] > LAZY_TAU))) {      // wave-uniform, rare after the first tiles
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 float mx = tmax[qb];
                 mx = fmaxf(mx, __shfl_xor(mx, 16));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float mn = fmaxf(m_run[qb], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - mn);   // first tile: 2^(-inf) = 0 on zero accumulators
-                m_run[qb] = mn;
+                // first tile: the reference becomes the tile's row maximum whatever its sign (o and l are still zero);
+                // later: it is only ever raised
+                const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_run[qb] += delta;
                 l_run[qb] *= alpha;
 #pragma unroll
                 for (int n = 0; n < ND; ++n)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[qb][n][r] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[qb][kb][r] -= delta;
             }
         }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            const float shift = bh[qb] - m_run[qb];
             float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[qb][kb][r] + shift);
+                    const float pv = __builtin_amdgcn_exp2f(s[qb][kb][r]);
                     rs += pv;
                     // contraction slot (m, g*8 + j): j < 4 -> key block 2m, reg j ; j >= 4 -> key block 2m+1, reg j-4
                     set_frag<T>(pf[qb][kb >> 1], (kb & 1) * 4 + r, pv);

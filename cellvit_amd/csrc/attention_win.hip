@@ -391,8 +391,9 @@ struct AttnwpGeom {
     static constexpr int NDMA = (WKEYS * LPPR + 63) / 64;
     static constexpr int KROWS = (NDMA * 64 + LPPR - 1) / LPPR;
     static constexpr int KIMG = KROWS * (HD + 8);       // halves per K image
+    static constexpr int PWR = 48;                      // halves per row of the kw-term staging area (see the kernel: skewed, unconditional writes)
     static constexpr size_t lds_bytes() {
-        return (size_t)(2 * KIMG + HD * (WKEYS + 4) + WKEYS * 40 + (PNT / 64) * WQW * 40 + 64 * (HDP + 8)) * sizeof(half_t);
+        return (size_t)(2 * KIMG + HD * (WKEYS + 4) + WKEYS * 40 + (PNT / 64) * 32 * PWR + 64 * (HDP + 8)) * sizeof(half_t);
     }
 };
 
@@ -428,8 +429,8 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
     half_t* Ks0 = reinterpret_cast<half_t*>(smemw);     // 2 x [KROWS][PKP]
     half_t* Vts = Ks0 + 2 * GM::KIMG;                   // [HD][PVF]
     half_t* Es = Vts + HD * PVF;                        // [208][PE1]
-    half_t* Rc = Es + WKEYS * PE1;                      // [256][PE1]
-    half_t* Ts = Rc + (PNT / 64) * WQW * PE1;           // [64][PT]
+    half_t* Wr = Es + WKEYS * PE1;                      // [8 waves][2 query blocks][16][PWR]: the kw terms of a query block, skewed (below)
+    half_t* Ts = Wr + (PNT / 64) * 32 * GM::PWR;        // [64][PT]
     const unsigned ldsK = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smemw;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -442,7 +443,6 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
 
     // ---- once per workgroup: zero the V^T image (pad columns and keys past nk stay zero for good), stage E and the tables
     if (!VRM) for (int i = tid; i < HD * PVF / 4; i += PNT) reinterpret_cast<unsigned long long*>(Vts)[i] = 0ull;
-    for (int i = tid; i < (PNT / 64) * WQW * PE1 / PE; i += PNT) store_piece(Rc + i * PE, zero_piece());
     if (BIAS) {
         const half_t* __restrict__ prepE = reinterpret_cast<const half_t*>(p.win_prep);
         const half_t* __restrict__ prepT = prepE + WKEYS * 32;
@@ -508,8 +508,10 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
     constexpr int VN = VRM == 2 ? 1 : (VRM == 1 ? VNR : (HD * VPPR + PNT - 1) / PNT);
     Piece vreg[VN];
     half8_t qf[2][NKS];
-    const int q0 = wave * WQW;
-    const bool wave_active = q0 < p.L;
+    // Query blocks are WINDOW ROWS (round 5): block qb of wave w holds the KW <= 16 queries of grid row qy = 2 w + qb (lane column li = qx;
+    // columns >= KW idle).  14 x 14 windows: 14 blocks of 14 on 7 waves — the same two blocks per wave as 13 blocks of 16 — and qy is
+    // wave-uniform, qx the lane's own column: no per-lane divisions anywhere, and the kh term of the rel-pos bias needs no scatter (below).
+    const bool wave_active = 2 * wave < p.KH;
 
     auto load_v = [&](int sh) {
         if constexpr (VRM == 2) return;
@@ -563,11 +565,13 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         const half_t* __restrict__ Qg = Qb + (long)sh * p.L * HD;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            const int row = q0 + qb * 16 + li_;
+            const int qy = 2 * wave + qb;
+            const int row = qy * p.KW + li_;
+            const bool okq = qy < p.KH && li_ < p.KW;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const int d0 = ks * 32 + g_ * 8;
-                qf[qb][ks] = (row < p.L && d0 < HD) ? *reinterpret_cast<const half8_t*>(Qg + (long)row * HD + d0) : (half8_t)(0);
+                qf[qb][ks] = (okq && d0 < HD) ? *reinterpret_cast<const half8_t*>(Qg + (long)row * HD + d0) : (half8_t)(0);
             }
         }
     };
@@ -598,45 +602,53 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         asm volatile("" : "+s"(nk));
         asm volatile("" : "+v"(li), "+v"(g));
         if (wave_active) {
-            // ---- relcat rows of this wave's queries (see attnw_kernel)
+            // ---- rel-pos operands of this wave's two query blocks: bf[qb] = the B fragment of the bias step S^T += E . bf, lane (g, li) =
+            // slots 8g .. 8g+7 of query li.  Slot 8g + r carries the kh term for kh = KH-1 - (4g + r), slot 8g + 4 + r the kw term for
+            // kw = KW-1 - (4g + r) (E, prepared per layer, has its ones accordingly: attnw_prep_kernel, layout 1).
+            //   kh term: rel_h[q][kh] = q . Rh[qy - kh + KH-1] = q . Rh[qy + c], c = KH-1 - kh.  qy is the block's, so ONE MFMA chain against
+            //     table rows qy .. qy+15 leaves exactly c = 4g + r in accumulator register r of lane (g, li): the slots are filled from the
+            //     lane's own registers — no LDS, no scatter.
+            //   kw term: rel_w[q][kw] = q . Rw[qx - kw + KW-1]: the table row depends on the lane's own column, a Toeplitz band.  The wave
+            //     computes G[D][q] = q . Rw[D], D = 0 .. 31, and every lane stores its eight values UNCONDITIONALLY at the skewed position
+            //     D - qx + 16 of its query's row (48 halves): position 16 + c then holds kw = KW-1 - c for c = 0 .. KW-1, out-of-band
+            //     values land outside [16, 16 + KW) — inside the row, finite, and E is zero there.  Every position a lane reads back
+            //     (16 + 4g + r) is rewritten for every item, so the area needs no initialisation.
             half8_t bf[2];
             if (BIAS) {
-                // (every column < KH + KW of a valid query's row is rewritten per item; the rest of Rc was zeroed once.  Writes
-                // that fall outside the band go to the row's never-read pad column 32: no divergent stores)
-                half_t* myrc = Rc + (wave * WQW) * PE1;
                 const float inv_scale = 1.0f / p.scale;
+                half_t* wrows = Wr + (wave * 32) * GM::PWR;
+                half8_t tw[2][NKS];
 #pragma unroll
-                for (int tbl = 0; tbl < 2; ++tbl) {
-                    const int Ksz = tbl == 0 ? p.KH : p.KW;
-                    const int off = tbl == 0 ? 0 : p.KH;
+                for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                    for (int jb = 0; jb < 2; ++jb) {
-                        half8_t tfr[NKS];
+                    for (int ks = 0; ks < NKS; ++ks)
+                        tw[jb][ks] = *reinterpret_cast<const half8_t*>(Ts + (32 + jb * 16 + li) * PT + ks * 32 + g * 8);
 #pragma unroll
-                        for (int ks = 0; ks < NKS; ++ks)
-                            tfr[ks] = *reinterpret_cast<const half8_t*>(Ts + (tbl * 32 + jb * 16 + li) * PT + ks * 32 + g * 8);
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int qy = 2 * wave + qb;               // (< 16: table rows qy + li < 32, the rows past 2 KH - 2 are zero)
+                    f32x4 ah = (f32x4)(0.f), aw0 = (f32x4)(0.f), aw1 = (f32x4)(0.f);
 #pragma unroll
-                        for (int qb = 0; qb < 2; ++qb) {
-                            f32x4 acc = (f32x4)(0.f);
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        const half8_t th = *reinterpret_cast<const half8_t*>(Ts + (qy + li) * PT + ks * 32 + g * 8);
+                        ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, qf[qb][ks], ah, 0, 0, 0);
+                        aw0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(tw[0][ks], qf[qb][ks], aw0, 0, 0, 0);
+                        aw1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(tw[1][ks], qf[qb][ks], aw1, 0, 0, 0);
+                    }
+                    half_t* wr = wrows + (qb * 16 + li) * GM::PWR + (16 + 4 * g - li);       // position of D = 4g: D - qx + 16
 #pragma unroll
-                            for (int ks = 0; ks < NKS; ++ks)
-                                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfr[ks], qf[qb][ks], acc, 0, 0, 0);
-                            const int q = q0 + qb * 16 + li;
-                            const int qy = q / p.KW, qx = q - qy * p.KW;
-                            const int c = (tbl == 0 ? qy : qx) + Ksz - 1 - jb * 16 - g * 4;
-                            half_t* rrow = myrc + (qb * 16 + li) * PE1;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int kk = c - r;               // 0 <= kk < Ksz implies a valid table row jj < 2 Ksz - 1
-                                const bool ok = (unsigned)kk < (unsigned)Ksz && q < p.L;
-                                rrow[ok ? off + kk : 32] = (half_t)(acc[r] * inv_scale);
-                            }
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        wr[r] = (half_t)(aw0[r] * inv_scale);
+                        wr[16 + r] = (half_t)(aw1[r] * inv_scale);
+                        bf[qb][r] = (half_t)(ah[r] * inv_scale);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) bf[qb] = *reinterpret_cast<const half8_t*>(myrc + (qb * 16 + li) * PE1 + g * 8);
+                for (int qb = 0; qb < 2; ++qb) {
+                    const half4_t w4 = *reinterpret_cast<const half4_t*>(wrows + (qb * 16 + li) * GM::PWR + 16 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bf[qb][4 + r] = w4[r];
+                }
             }
 
             // ---- S^T for all 13 key blocks (rows past nk hold finite clamped data and are masked below), k-step outermost,
@@ -785,19 +797,18 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
             const int s_idx = it / p.heads, h = it - s_idx * p.heads;
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
-                const int qg = q0 + qb * 16 + li;
-                if (qg >= p.L) continue;
+                const int qy = 2 * wave + qb;                // the block's grid row (wave-uniform), li = the lane's grid column
+                if (qy >= p.KH || li >= p.KW) continue;
                 long row;
-                if (p.win > 0) {
+                if (p.win > 0) {                            // window mode: KH = KW = win
                     const int nw = p.nwx * p.nwy;
                     const int b = s_idx / nw, w = s_idx - b * nw;
                     const int wy = w / p.nwx, wx = w - wy * p.nwx;
-                    const int py = qg / p.win, px = qg - py * p.win;
-                    const int gy = wy * p.win + py, gx = wx * p.win + px;
+                    const int gy = wy * p.win + qy, gx = wx * p.win + li;
                     if (gy >= p.gh || gx >= p.gw) continue;
                     row = (long)b * p.ntok + gy * p.gw + gx;
                 } else {
-                    row = (long)s_idx * p.ntok + qg;
+                    row = (long)s_idx * p.ntok + qy * p.KW + li;
                 }
                 if constexpr (HD == 80) {
                     if (p.out8) { attn_store_mx8(p, o[qb], inv_l[qb], row, h, g); continue; }   // fp8 engine: MX-fp8 rows for the proj GEMM
@@ -821,14 +832,22 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
 
 // E and the fp16 tables, once per layer (they are the same for every workgroup of the layer)
 template <int HD>
+// layout 0 (attnw_kernel): E[key][kh | KH + kw];  layout 1 (attnwp_kernel, query blocks = window rows): slot 8g + r <-> kh = KH-1 - (4g + r),
+// slot 8g + 4 + r <-> kw = KW-1 - (4g + r) — the order in which that kernel's lanes hold the two terms (see there)
 __global__ void attnw_prep_kernel(const float* __restrict__ tab_h, const float* __restrict__ tab_w, int KH, int KW, int nk,
-                                  half_t* __restrict__ prep) {
+                                  half_t* __restrict__ prep, int layout) {
     constexpr int HDP = (HD + 31) / 32 * 32;
     const int tid = threadIdx.x + blockIdx.x * blockDim.x, nth = blockDim.x * gridDim.x;
     for (int i = tid; i < WKEYS * 32; i += nth) {
         const int r = i >> 5, col = i & 31;
         const int kh = r / KW, kw = r - kh * KW;
-        prep[i] = (half_t)((r < nk && (col == kh || col == KH + kw)) ? 1.f : 0.f);
+        bool one;
+        if (layout == 0) one = col == kh || col == KH + kw;
+        else {
+            const int c = 4 * (col >> 3) + (col & 3);
+            one = (col & 4) ? (kw == KW - 1 - c) : (kh == KH - 1 - c);
+        }
+        prep[i] = (half_t)((r < nk && one) ? 1.f : 0.f);
     }
     half_t* T = prep + WKEYS * 32;
     for (int i = tid; i < 2 * 32 * HDP; i += nth) {
@@ -851,9 +870,9 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    if (BIAS) hipLaunchKernelGGL((attnw_prep_kernel<HD>), dim3(8), dim3(256), 0, stream, p.tab_h, p.tab_w, p.KH, p.KW, p.nk,
-                                 reinterpret_cast<half_t*>(p.win_prep));
     static const int persistent = cva_env_int("CVA_ATTNW_P", 1);
+    if (BIAS) hipLaunchKernelGGL((attnw_prep_kernel<HD>), dim3(8), dim3(256), 0, stream, p.tab_h, p.tab_w, p.KH, p.KW, p.nk,
+                                 reinterpret_cast<half_t*>(p.win_prep), (persistent && p.nk > (WNKB - 1) * 16) ? 1 : 0);
     // (no batch term in this test: the layouts a geometry fixes — row-major V, MX-fp8 rows — are decided once for max_batch and must hold
     //  for every smaller batch of the same geometry; with fewer items than CUs the persistent grid is simply smaller)
     if (BIAS && persistent && p.nk > (WNKB - 1) * 16) {
