@@ -309,7 +309,7 @@ def extras(model, step, B, dev, make_step=None):
         r = bs.run(tiles=144, batch=16, model="samh", real_model=model)
         out["slide"] = {k: r[k] for k in ("tiles", "batch", "ranks", "tile_loop_tiles_per_s_rank0", "cells_written", "margin_records",
                                           "margin_kept", "exchange_s", "stitch_s", "to_dicts_s", "write_s", "slide_total_s",
-                                          "slide_tiles_per_s", "output_MB")}
+                                          "slide_tiles_per_s", "output_MB", "tail_s", "tail_route")}
         out["slide_note"] = ("tools/bench_slide.py on a 12 x 12-tile synthetic slide (BASELINE.json configs[3] route on one GPU): the forward runs "
                              "for real, its planes are replaced by crops of a periodic synthetic nucleus world (~800 cells per tile)")
     except Exception as e:      # noqa: BLE001

@@ -103,6 +103,11 @@ SYMBOLS.update({
     "cv_write_cells_json": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int] + [C.c_void_p] * 11),
     "cv_write_geojson": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
+    "cv_render_cells": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 11 + [C.POINTER(C.c_void_p)]),
+    "cv_textbuf_compact": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "cv_textbuf_free": (None, [C.c_void_p]),
+    "cv_write_rows": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32),
+                                C.POINTER(C.c_int64)]),
     "cv_stitch_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.POINTER(C.c_int32), C.c_void_p]),
 })

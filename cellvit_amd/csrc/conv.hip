@@ -529,6 +529,210 @@ __global__ __launch_bounds__(NTH4, 2) void conv3x3_halo4_kernel(const GemmParams
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Persistent variant with the filter RESIDENT in LDS, for the layers whose whole filter fits next to a halo ring: Cin = 32 / 64 -> 64 output
+// channels, i.e. the full-resolution 64-channel layers (decoder0.1 and the last convolution of every branch, with the fused 1x1 head).
+// Round 5.  In conv3x3_halo4_kernel above every workgroup stages, per 16 x 32-pixel tile, 39.9 KB of halo AND 36.9 KB of filter taps per
+// 32-channel chunk — the same taps for all 2048 tiles of an image — and then waits for them (one stage per workgroup, two workgroups per CU
+// hiding each other's waits): those layers ran at 2 - 3.4 TB/s and 30 - 35 % of the MFMA rate, far from both roofs (profiles/r04_p_*).
+// Here ONE workgroup of 8 waves per CU walks the tiles grid-stride; the filter (36.9 KB per chunk) is staged once per workgroup; the halo of
+// the next chunk — of this tile or of the workgroup's next tile — is in flight in the other of two 39.9-KB slots while the nine taps of the
+// current chunk multiply, so LDS-DMA traffic per tile falls from 153 KB to 80 KB and no tile starts with an exposed round trip.
+// Wave w owns image rows 2w, 2w+1 of the tile (64 pixels x 64 output channels), fragment pipeline one tap ahead as in conv3x3_halo_kernel;
+// operands exchanged + permuted filter rows as in conv3x3_halo4_kernel, so the epilogue (bias, ReLU, 16-byte NHWC stores or the fused head's
+// two MFMAs per slab + argmax) runs from the accumulators.  The epilogue's stores are never waited for: each wave retires its DMA pieces
+// (vmcnt(0)) at the END of a chunk's taps, before the stores are issued; they drain under the next chunk.
+template <int NCH>
+__global__ __launch_bounds__(NTH, 2) void conv3x3_res_kernel(const GemmParams p, const int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW = smem;                            // [NCH][9 taps][64 rows][64 B]
+    unsigned char* sH = smem + NCH * W_BYTES;            // two halo slots
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = p.H, W = p.Wd;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ctot = p.C1;                               // single source (host)
+
+    const half_t* __restrict__ S1 = reinterpret_cast<const half_t*>(p.A);
+    const half_t* __restrict__ Wp = reinterpret_cast<const half_t*>(p.W);
+    const half_t* __restrict__ Zp = reinterpret_cast<const half_t*>(p.zero);
+
+    // ---- the filter, once: LDS row n of a tap holds output channel cout_of_row(n) (direct epilogue, see conv3x3_halo4_kernel)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int i = 0; i < MAX_W; ++i) {
+            const int k = wave + NWAVE * i;
+            if (k < W_INSTR) {                           // wave-uniform
+                const int tap = k >> 2, n = (k & 3) * 16 + (lane >> 2);
+                const half_t* s = Wp + (long)cout_of_row(n) * p.ldw + tap * ctot + ((lane & 3) ^ swz(n)) * 8 + c * 32;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                                 (__attribute__((address_space(3))) void*)(sW + c * W_BYTES + k * 1024), 16, 0, 0);
+            }
+        }
+
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem;
+    unsigned a_base[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        a_base[i] = lds0 + (unsigned)(NCH * W_BYTES) +
+                    (unsigned)(((2 * wave + (i >> 1) + 1) * HW_ + ((i & 1) * 16 + li + 1) - (HW_ + 1)) * 64) + ((unsigned)(g & 1) << 4);
+    unsigned a_u5 = 0u;
+    {
+        const int r8 = ((2 * wave + 1) * HW_ + li + 1) & 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a_u5 |= (unsigned)((((r8 + e) >> 2) & 1) ^ ((g >> 1) & 1)) << (5 + e);
+    }
+    unsigned b_ad[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int n = j * 16 + li; b_ad[j] = lds0 + n * 64 + ((g ^ swz(n)) << 4); }
+
+    // tile id of the workgroup's it-th tile: every XCD walks a contiguous range (neighbouring tiles share halo columns / rows through its L2)
+    auto tile_of = [&](int it, int& b, int& y0, int& x0) {
+        int t = xcd_remap((int)blockIdx.x + it * (int)gridDim.x, ntiles);
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y; b = t / tiles_y;
+        y0 = ty * TH; x0 = tx * TW;
+    };
+    // halo of chunk c of tile (b, y0, x0) -> slot (descriptors recomputed per stage: a few dozen VALU instructions per chunk)
+    auto stage_halo = [&](int b, int y0, int x0, int c, int slot) {
+#pragma unroll
+        for (int i = 0; i < MAX_H; ++i) {
+            const int k = wave + NWAVE * i;
+            if (k < HALO_INSTR) {                        // wave-uniform
+                const int hp = k * 16 + (lane >> 2);
+                const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                const bool ok = hp < HALO_PIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const half_t* s = ok ? S1 + (long)((b * H + gy) * W + gx) * ctot + c * 32 + ((lane & 3) ^ swz(hp)) * 8 : Zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                                 (__attribute__((address_space(3))) void*)(sH + slot * HALO_BYTES + k * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- epilogue constants
+    const bool fuse = p.head_W != nullptr;
+    half8_t wf[2]; f32x4 hb4 = (f32x4)(0.f);
+    wf[0] = (half8_t)(0); wf[1] = (half8_t)(0);
+    if (fuse) {
+        if (li < p.head_nout) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wf[ks][e] = (half_t)p.head_W[li * 64 + ks * 32 + g * 8 + e];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (g * 4 + r < p.head_nout) hb4[r] = p.head_b[g * 4 + r];
+    }
+    float bv[16];                                   // bias of the lane's channels: fragment j -> (j >> 1)*32 + g*8 + (j & 1)*4 + r
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[j * 4 + r] = p.bias ? p.bias[(j >> 1) * 32 + g * 8 + (j & 1) * 4 + r] : 0.f;
+    const bool relu = p.act == ACT_RELU;
+
+    half8_t Af[2][4], Bf[2][4];
+#define CR_MMA_TAP(S)                                                                                           \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf[S][j], Af[S][i], acc[i][j], 0, 0, 0);     \
+    } while (0)
+#define CR_STEP(TAP)                                                                                            \
+    do {                                                                                                        \
+        if ((TAP) < 8) { CV_READ_TAP(((TAP) + 1) % 9, ((TAP) + 1) & 1, 0); CV_WAIT(8, (TAP) & 1); }             \
+        else { CV_WAIT(0, (TAP) & 1); }                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        CR_MMA_TAP((TAP) & 1);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
+
+    int it = 0;
+    int b, y0, x0;
+    tile_of(0, b, y0, x0);
+    stage_halo(b, y0, x0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int slot = 0;
+    for (;;) {
+        const bool has_next = (int)blockIdx.x + (it + 1) * (int)gridDim.x < ntiles;      // block-uniform
+        int nb = 0, ny0 = 0, nx0 = 0;
+        if (has_next) tile_of(it + 1, nb, ny0, nx0);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            __syncthreads();                             // this chunk's halo (and, the first time, the filter) has landed for every wave;
+                                                         // every wave has finished reading the other slot
+            unsigned a_cur[4], b_cur[4];                 // (opaque: the 36 tap addresses must not be hoisted)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a_cur[i] = a_base[i] + (unsigned)slot * HALO_BYTES; b_cur[i] = b_ad[i] + c * W_BYTES;
+                asm volatile("" : "+v"(a_cur[i]), "+v"(b_cur[i]));
+            }
+            CV_READ_TAP(0, 0, 0);
+            if (c + 1 < NCH) stage_halo(b, y0, x0, c + 1, slot ^ 1);
+            else if (has_next) stage_halo(nb, ny0, nx0, 0, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            CR_STEP(0); CR_STEP(1); CR_STEP(2); CR_STEP(3); CR_STEP(4); CR_STEP(5); CR_STEP(6); CR_STEP(7); CR_STEP(8);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next halo (they had nine taps to land)
+            slot ^= 1;
+        }
+        // ---- epilogue of tile (b, y0, x0) from the accumulators; its stores drain under the next chunk
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = y0 + 2 * wave + (i >> 1);
+            const int x = x0 + (i & 1) * 16 + li;
+            const bool valid = y < H && x < W;
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = acc[i][j][r] + bv[j * 4 + r];
+                    v[j * 4 + r] = relu ? fmaxf(t, 0.f) : t;
+                }
+            half8_t hq[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hq[q][e] = (half_t)v[q * 8 + e];
+            if (!fuse) {
+                half_t* o = reinterpret_cast<half_t*>(p.out) + (((long)b * H + y) * W + x) * p.ldc + g * 8;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (valid) *reinterpret_cast<half8_t*>(o + q * 32) = hq[q];
+                continue;
+            }
+            f32x4 ha = hb4;
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], hq[0], ha, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], hq[1], ha, 0, 0, 0);
+            const long hwp = (long)H * W, pix = (long)y * W + x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (valid && g * 4 + r < p.head_nout) p.head_logits[((long)b * p.head_nout + g * 4 + r) * hwp + pix] = ha[r];
+            float bvv = ha[0]; int best = g * 4;
+            if (g != 0 && !(g * 4 < p.head_narg)) bvv = -INFINITY;
+#pragma unroll
+            for (int r = 1; r < 4; ++r)
+                if (g * 4 + r < p.head_narg && ha[r] > bvv) { bvv = ha[r]; best = g * 4 + r; }
+            const float ov = __shfl_xor(bvv, 16);
+            const int oi = __shfl_xor(best, 16);
+            if (p.head_narg > 4 && ov > bvv) best = oi;
+            if (g == 0 && valid && p.head_argmax) p.head_argmax[(long)b * hwp + pix] = (uint8_t)best;
+        }
+        if (!has_next) break;
+        ++it; b = nb; y0 = ny0; x0 = nx0;
+    }
+#undef CR_STEP
+#undef CR_MMA_TAP
+}
+
 }  // namespace
 
 // Returns -1 when the layer does not fit this kernel (caller uses the implicit-GEMM path).
@@ -543,6 +747,27 @@ int launch_conv3x3_halo(const GemmParams& p, int batch, hipStream_t stream) {
         attr8 = true;
     }
     const int tiles = batch * ((p.H + TH - 1) / TH) * ((p.Wd + TW - 1) / TW);
+    // Cin 32 / 64 -> 64 channels, one source, fp16 output or the fused head: the persistent kernel with the filter resident in LDS
+    static const int res_on = cva_env_int("CVA_CONV_RES", 1);
+    if (res_on && p.N == 64 && p.C2 == 0 && (p.C1 == 32 || p.C1 == 64) && !p.out_f32 && p.ldc == 64 && tiles >= 64) {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 256;
+        }
+        const int grid_r = tiles < n_cu ? tiles : n_cu;
+        if (p.C1 == 64) {
+            static bool a2 = false;
+            if (!a2) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_res_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return (int)hipGetLastError(); a2 = true; }
+            hipLaunchKernelGGL(conv3x3_res_kernel<2>, dim3(grid_r), dim3(NTH), 2 * W_BYTES + 2 * HALO_BYTES, stream, p, tiles);
+        } else {
+            static bool a1 = false;
+            if (!a1) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_res_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return (int)hipGetLastError(); a1 = true; }
+            hipLaunchKernelGGL(conv3x3_res_kernel<1>, dim3(grid_r), dim3(NTH), W_BYTES + 2 * HALO_BYTES, stream, p, tiles);
+        }
+        return (int)hipGetLastError();
+    }
     const dim3 grid(tiles * ((p.N + 63) / 64));
     // few channel chunks per tile: the 4-wave single-stage kernel, two workgroups per CU (see conv3x3_halo4_kernel)
     static const int halo4_max_chunks = cva_env_int("CVA_CONV_HALO4", 8);

@@ -186,8 +186,7 @@ class SlideCells:
 
     def select(self, idx: np.ndarray) -> "SlideCells":
         offs, lens = self.contour_slices()
-        parts = [self.ct[offs[i]:offs[i] + lens[i]] for i in idx]
-        ct = np.concatenate(parts).astype(np.int32) if parts else np.zeros((0, 2), np.int32)
+        ct = S.gather_segments(self.ct.reshape(-1, 2), offs, lens, idx).astype(np.int32) if len(idx) else np.zeros((0, 2), np.int32)
         tok = self.tokens[torch.as_tensor(idx, dtype=torch.long, device=self.tokens.device)] if self.tokens is not None else None
         return SlideCells(self.ir[idx], self.fr[idx], ct, tok)
 
@@ -369,10 +368,12 @@ class CellSegmentationInference:
 
     # ------------------------------------------------------------------------------------------
     def run_tiles(self, wsi: PatchedSlide, tile_ids: List[int], batch_size: int, patch_size: int = 1024,
-                  overlap: int = 64, num_workers: Optional[int] = None) -> Tuple[SlideCells, List[str], dict]:
+                  overlap: int = 64, num_workers: Optional[int] = None, tail=None) -> Tuple[SlideCells, List[str], dict]:
         """The tile loop (cell_detection.py:306-421) for one rank's tiles.  Per batch: raw u8 tiles -> forward (HIP) ->
         post-processing on the argmax planes the forward wrote (HIP) -> cell-token pooling (HIP); then the record / contour
-        arrays go to pinned host buffers on a copy stream.  Host work of batch k (array unpacking) overlaps the GPU work of k+1."""
+        arrays go to pinned host buffers on a copy stream.  Host work of batch k (array unpacking) overlaps the GPU work of k+1.
+        `tail` (a `tail.SlideTail`): every finished batch is handed to the streaming slide tail — token rows leave the device per
+        batch, geometry and JSON text are prepared by its worker threads while the loop runs; the returned cells then carry no tokens."""
         nuclei_types = self.run_conf["dataset_config"]["nuclei_types"]
         obj, ks = _params(int(wsi.metadata["magnification"]))
         parts: List[SlideCells] = []
@@ -451,10 +452,17 @@ class CellSegmentationInference:
                     t_.record_stream(copy_stream)
                 if tok is not None:
                     tok.record_stream(torch.cuda.current_stream(self.device))
-            o = 0
-            for ir, fr, ct, n in tiles_out:
-                parts.append(SlideCells(ir, fr, ct, tok[o:o + n]))
-                o += n
+            if tail is not None:
+                if tiles_out:
+                    tail.add_batch(ids[0], np.concatenate([t[0] for t in tiles_out]), np.concatenate([t[1] for t in tiles_out]),
+                                   np.concatenate([t[2] for t in tiles_out]).reshape(-1, 2), tok, copy_stream)
+                for ir, fr, ct, n in tiles_out:
+                    parts.append(SlideCells(ir, fr, ct, None))
+            else:
+                o = 0
+                for ir, fr, ct, n in tiles_out:
+                    parts.append(SlideCells(ir, fr, ct, tok[o:o + n]))
+                    o += n
             stats["tiles"] += len(ids)
 
         t0 = time.perf_counter()
@@ -498,9 +506,14 @@ class CellSegmentationInference:
             raise err
 
     def process_wsi(self, wsi: PatchedSlide, subdir_name: Optional[str] = None, patch_size: int = 1024,
-                    overlap: int = 64, batch_size: int = 8, geojson: bool = False, defer_write: bool = False) -> dict:
+                    overlap: int = 64, batch_size: int = 8, geojson: bool = False, defer_write: bool = False,
+                    stream_tail: bool = True) -> dict:
         """`defer_write`: hand the files of this slide to a writer thread and return (process_dataset: the files of slide k are
-        written — mostly outside the GIL — while the tile loop of slide k+1 runs); `wait_for_writers()` joins it."""
+        written — mostly outside the GIL — while the tile loop of slide k+1 runs); `wait_for_writers()` joins it.
+        `stream_tail` (default): the streaming slide tail (`tail.SlideTail`) — token rows, geometry and JSON text of every batch are
+        prepared while the tile loop runs, after it only margin records are exchanged and the files are assembled from chunks;
+        False: the batch route (`finalize_slide` + `write_outputs`), which is also what the tests check the streaming route against."""
+        import time
         import torch.distributed as dist
         dd = dist.is_available() and dist.is_initialized()
         rank = dist.get_rank() if dd else 0
@@ -509,44 +522,230 @@ class CellSegmentationInference:
         outdir = Path(wsi.patched_slide_path) / "cell_detection" / (subdir_name or "")
         outdir.mkdir(exist_ok=True, parents=True)
         my_tiles = S.shard_tiles(len(wsi.patches_list), rank, world, block=batch_size)
-        local, processed, stats = self.run_tiles(wsi, my_tiles, batch_size, patch_size, overlap)
+        exch_dev = self.device if (dd and dist.get_backend() == "nccl") else torch.device("cpu")
+        mps, mds = wsi.metadata["patch_size"], wsi.metadata["downsampling"]
+        tail = None
+        if stream_tail:
+            from .tail import SlideTail
+            tail = SlideTail(mps, mds, overlap, self.device, keep_geometry=geojson)
+        local, processed, stats = self.run_tiles(wsi, my_tiles, batch_size, patch_size, overlap, tail=tail)
         self.logger.info(f"[rank {rank}/{world}] {stats['tiles']} tiles in {stats['t_loop']:.2f} s "
                          f"({stats['tiles'] / max(stats['t_loop'], 1e-9):.1f} tiles/s), cells before cleaning: {len(local)}")
-        exch_dev = self.device if (dd and dist.get_backend() == "nccl") else torch.device("cpu")
         timings: dict = {}
         # a writer failure of the PREVIOUS slide (rank 0 only) is agreed on by all ranks before this slide's first collective:
         # everyone aborts together instead of the other ranks hanging in the next exchange
         self._agree_on_writer_error(exch_dev)
-        allc, _ = finalize_slide(local, wsi.metadata["patch_size"], wsi.metadata["downsampling"], overlap,
-                                 device=exch_dev, logger=self.logger, compute_device=self.device, timings=timings, want_dicts=False,
-                                 gather_to=0)
+        if tail is None:
+            allc, _ = finalize_slide(local, mps, mds, overlap, device=exch_dev, logger=self.logger, compute_device=self.device,
+                                     timings=timings, want_dicts=False, gather_to=0)
+            job = None
+        else:
+            try:
+                job = self._finish_streamed(tail, exch_dev, mps, mds, overlap, geojson, timings)
+            except BaseException:
+                tail.close()
+                raise
         if world > 1:
             gathered: List[Optional[list]] = [None] * world
             dist.all_gather_object(gathered, processed)       # tile names only (a few bytes per tile)
             order = {f"{m['row']}_{m['col']}": i for i, m in enumerate(wsi.all_patch_metadata[n] for n in wsi.patches_list)}
             processed = sorted((p for part in gathered for p in part), key=lambda k: order.get(k, 1 << 30))
-        import time
         t0 = time.perf_counter()
         self.wait_for_writers()                                   # at most one slide's files in flight
         if rank == 0:
-            wargs = (outdir, wsi.metadata, processed, nuclei_types, allc, geojson, wsi.metadata["patch_size"],
-                     wsi.metadata["downsampling"], overlap)
+            if tail is None:
+                wargs = (outdir, wsi.metadata, processed, nuclei_types, allc, geojson, mps, mds, overlap)
+                target = lambda: write_outputs(*wargs)     # noqa: E731
+            else:
+                target = lambda: write_outputs_streamed(outdir, wsi.metadata, processed, nuclei_types, job, geojson, tail)   # noqa: E731
             if defer_write:
                 import threading
 
                 def _write():
                     try:
-                        write_outputs(*wargs)
+                        target()
                     except BaseException as e:      # noqa: BLE001  (re-raised by wait_for_writers)
                         self._writer_error = e
                 self._writer = threading.Thread(target=_write, name="cellvit-writers")
                 self._writer.start()
             else:
-                write_outputs(*wargs)
+                target()
+        elif tail is not None:
+            tail.close()
         timings["write_s"] = time.perf_counter() - t0
-        stats.update({"n_cells": int(timings.get("n_cells_total", len(allc) if allc is not None else 0)),
+        stats.update({"n_cells": int(timings.get("n_cells_total", len(allc) if (tail is None and allc is not None) else 0)),
                       "cells_before_cleaning": len(local), "outdir": str(outdir), **timings})
         return stats
+
+    def _finish_streamed(self, tail, exch_dev, patch_size, downsampling, overlap, geojson, timings: dict) -> Optional[dict]:
+        return finish_streamed(tail, exch_dev, self.device, patch_size, downsampling, overlap, geojson, timings, self.logger)
+
+
+def finish_streamed(tail, exch_dev, compute_device, patch_size, downsampling, overlap, geojson, timings: dict, logger=None) -> Optional[dict]:
+    """After the tile loop, streaming route: exchange ONLY the margin records (one all-gatherv), one global de-duplication (the same
+    deterministic computation on every rank), keep masks per batch, then the writer's gather of the kept chunks (point to point, exact
+    sizes; nothing on one rank).  Returns the writer's job (chunk lists in slide order) on rank 0, None elsewhere."""
+    import time
+    import torch.distributed as dist
+    from .stitch import stitch_margin_records
+    dd = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if dd else 1
+    rank = dist.get_rank() if dd else 0
+    t_start = time.perf_counter()
+    mi, mf, mc = tail.local_margin()                                   # (waits for the batches' worker jobs)
+    t_ready = time.perf_counter()
+    gi, gf, gc = S.all_gather_margin_records(mi, mf, mc, device=exch_dev)
+    perm = S.canonical_order(gi)
+    gi, gf, gc = S.reorder_records(gi, gf, gc, perm)
+    t_gather = time.perf_counter()
+    keep_g = stitch_margin_records(gi, gc, patch_size, downsampling, overlap, device=compute_device or exch_dev, logger=logger)
+    t_stitch = time.perf_counter()
+    n_mine = tail.set_survivors(gi[keep_g])
+    n_total = sum(S.all_gather_int(n_mine, exch_dev)) if world > 1 else n_mine
+    D = max(S.all_gather_int(tail.token_dim, exch_dev)) if world > 1 else tail.token_dim
+    sh = tail.kept_shard()
+    sent = recv = 0
+    shards = [sh]
+    if world > 1:
+        shards, sent, recv = _gather_shards_to(sh, D, 0, exch_dev)
+    job = None
+    if rank == 0:
+        job = _merge_shards(shards, D)
+        job["n"] = int(n_total)
+        if geojson and world > 1:
+            job["geo"] = None            # (remote ranks keep no f64 geometry: the optional geojson pair is rendered from gathered records)
+    if geojson and world > 1:
+        mine = SlideCells.concat([SlideCells(b.ir, b.fr, b.ct).select(np.nonzero(b.keep)[0]) for b in tail.batches]) if tail.batches else SlideCells()
+        got, s_, r_ = S.gather_records_to(mine.ir, mine.fr, mine.ct, 0, device=exch_dev)
+        sent += s_; recv += r_
+        if got is not None:
+            ai, af, ac = got
+            p2 = S.canonical_order(ai)
+            ai, af, ac = S.reorder_records(ai, af, ac, p2)
+            job["geo_cells"] = SlideCells(ai, af, ac, None)
+    t_collect = time.perf_counter()
+    if logger:
+        logger.info(f"[rank {rank}] cells after cleaning: {n_total} (margin cells exchanged: {len(gi)})")
+    timings.update({"margin_records": int(len(gi)), "margin_kept": int(len(keep_g)), "n_cells_total": int(n_total),
+                    "margin_bytes_all_gathered": int(gi.nbytes + gf.nbytes + gc.nbytes), "writer_gather_bytes_sent": int(sent),
+                    "writer_gather_bytes_received": int(recv), "tail_wait_workers_s": t_ready - t_start,
+                    "exchange_s": (t_gather - t_ready) + (t_collect - t_stitch), "stitch_s": t_stitch - t_gather, "to_dicts_s": 0.0})
+    return job
+
+
+def _gather_shards_to(sh: dict, D: int, dst: int, dev):
+    """The writer's gather of the streaming route: every rank's kept chunks, concatenated per rank (text bytes, token rows, positions,
+    contour points, contour lengths) + per-batch keys / counts / text lengths, point to point to `dst`.  Returns (list of shards in
+    rank order on `dst` — the writer's own shard stays as chunk lists with masks, the others are slices of the received tensors —,
+    bytes sent, bytes received)."""
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    sent = recv = 0
+
+    def g(t):
+        nonlocal sent, recv
+        parts, s_, r_ = S._gather_var_to(t.to(dev), dst)
+        sent += s_; recv += r_
+        return parts
+
+    def cat_kept(pairs, width, dtype):
+        rows = [(torch.from_numpy(a) if isinstance(a, np.ndarray) else a)[torch.from_numpy(k.astype(bool))] for a, k in pairs if a is not None and len(a)]
+        return torch.cat(rows) if rows else torch.zeros((0, width), dtype=dtype)
+
+    nb = len(sh["keys"])
+    meta = torch.from_numpy(np.stack([sh["keys"], sh["counts"], np.asarray([len(c) for c in sh["text_cells"]], np.int64),
+                                      np.asarray([len(c) for c in sh["text_det"]], np.int64),
+                                      np.asarray([int(l.sum()) for l in sh["lens"]], np.int64)], 1).reshape(nb, 5))
+    is_dst = rank == dst
+    p_meta = g(meta)
+    own = lambda t: torch.zeros((0,) + tuple(t.shape[1:]), dtype=t.dtype) if is_dst else t   # noqa: E731  (the writer keeps its own chunks in place)
+    text0 = torch.from_numpy(np.concatenate(sh["text_cells"]) if nb else np.zeros(0, np.uint8))
+    text1 = torch.from_numpy(np.concatenate(sh["text_det"]) if nb else np.zeros(0, np.uint8))
+    p_t0, p_t1 = g(own(text0)), g(own(text1))
+    p_tok = g(own(cat_kept(sh["tok"], D, torch.float32))) if D > 0 else None
+    p_pos = g(own(cat_kept(sh["pos"], 2, torch.float32)))
+    p_cont = g(own(cat_kept(sh["cont"], 2, torch.float32)))
+    p_lens = g(own(torch.from_numpy(np.concatenate(sh["lens"]) if nb else np.zeros(0, np.int64))))
+    if not is_dst:
+        return None, sent, recv
+    shards = []
+    for r in range(dist.get_world_size()):
+        if r == dst:
+            shards.append(sh)
+            continue
+        m = p_meta[r].cpu().numpy().reshape(-1, 5)
+        cnt, l0, l1, lc = m[:, 1], m[:, 2], m[:, 3], m[:, 4]
+        t0, t1 = p_t0[r].cpu().numpy(), p_t1[r].cpu().numpy()
+        tok = p_tok[r].cpu() if p_tok is not None else None
+        pos, cont, lens = p_pos[r].cpu().numpy(), p_cont[r].cpu().numpy(), p_lens[r].cpu().numpy()
+        o0, o1, oc, ol = (np.concatenate([[0], np.cumsum(a)]) for a in (l0, l1, cnt, lc))
+        shards.append({"keys": m[:, 0], "counts": cnt,
+                       "text_cells": [t0[o0[i]:o0[i + 1]] for i in range(len(m))], "text_det": [t1[o1[i]:o1[i + 1]] for i in range(len(m))],
+                       "tok": [((tok[oc[i]:oc[i + 1]] if tok is not None else None), None) for i in range(len(m))],
+                       "pos": [(pos[oc[i]:oc[i + 1]], None) for i in range(len(m))],
+                       "cont": [(cont[ol[i]:ol[i + 1]], None) for i in range(len(m))],
+                       "lens": [lens[oc[i]:oc[i + 1]] for i in range(len(m))]})
+    return shards, sent, recv
+
+
+def _merge_shards(shards: List[dict], D: int) -> dict:
+    """All ranks' batches in slide order (first tile index of the batch): chunk lists for the writers."""
+    items = []
+    for sh in shards:
+        for i in range(len(sh["keys"])):
+            items.append((int(sh["keys"][i]), sh, i))
+    items.sort(key=lambda t: t[0])
+    pick = lambda name: [sh[name][i] for _, sh, i in items]   # noqa: E731
+    lens = [sh["lens"][i] for _, sh, i in items]
+    return {"D": D, "text_cells": pick("text_cells"), "text_det": pick("text_det"), "tok": pick("tok"), "pos": pick("pos"), "cont": pick("cont"),
+            "lens": np.concatenate(lens).astype(np.int64) if lens else np.zeros(0, np.int64)}
+
+
+def write_outputs_streamed(outdir: Path, wsi_metadata: dict, processed: List[str], nuclei_types: dict, job: dict, geojson: bool, tail) -> None:
+    """The writers of cell_detection.py:438-475 from the streaming route's chunk lists: the two JSON documents are header + chunks + footer
+    (byte for byte `cv_write_cells_json` of the kept cells), cells.pt a skip_data archive filled by parallel row writes (`tail.write_cells_pt_streamed`)."""
+    import threading
+    from . import tail as T
+    try:
+        meta = {"wsi_metadata": wsi_metadata, "processed_patches": processed, "type_map": nuclei_types}
+        header = json.dumps(meta, default=_np_default)[1:-1].encode("utf-8")
+        errors: List[BaseException] = []
+
+        def guarded(fn, *a):
+            try:
+                fn(*a)
+            except BaseException as e:      # noqa: BLE001
+                errors.append(e)
+        th = [threading.Thread(target=guarded, args=(T.write_json_chunks, outdir / "cells.json", header, job["text_cells"])),
+              threading.Thread(target=guarded, args=(T.write_json_chunks, outdir / "cell_detection.json", header, job["text_det"]))]
+        for t in th:
+            t.start()
+        n = int(job["n"])
+        if n:
+            T.write_cells_pt_streamed(outdir / "cells.pt", n, int(job["D"]), job["tok"] if job["D"] > 0 else [], job["pos"], job["cont"], job["lens"],
+                                      {"wsi_metadata": wsi_metadata, "nuclei_types": nuclei_types})
+        if geojson:
+            if job.get("geo_cells") is not None:
+                allc = job["geo_cells"]
+                write_geojson_pair(outdir, allc.geometry(wsi_metadata["patch_size"], wsi_metadata["downsampling"], tail.ov),
+                                   np.ascontiguousarray(allc.ir[:, S.I_TYPE].astype(np.int32)))
+            else:
+                cen, offs, cont, typ = [], [0], [], []
+                for b in sorted(tail.batches, key=lambda b: b.key):
+                    k = b.keep.astype(bool)
+                    c0, o0, ct0, t0 = b.geo
+                    lens = np.diff(o0)
+                    cen.append(c0[k]); typ.append(t0[k]); cont.append(ct0[np.repeat(k, lens)])
+                    offs.extend((offs[-1] + np.cumsum(lens[k])).tolist())
+                g = {"centroid": np.ascontiguousarray(np.concatenate(cen)) if cen else np.zeros((0, 2)),
+                     "ct_off": np.asarray(offs, np.int64), "contour": np.ascontiguousarray(np.concatenate(cont)) if cont else np.zeros((0, 2), np.int64)}
+                write_geojson_pair(outdir, g, np.ascontiguousarray(np.concatenate(typ).astype(np.int32)) if typ else np.zeros(0, np.int32))
+        for t in th:
+            t.join()
+        if errors:
+            raise errors[0]
+    finally:
+        tail.close()
 
 
 def pool_cell_tokens_fixed(tokens: torch.Tensor, recs: torch.Tensor, n_recs: torch.Tensor, patch_size: int,

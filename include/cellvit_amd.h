@@ -289,6 +289,24 @@ int cv_write_cells_json(const char* path, const char* header, int detection_only
  * reference's list after parsing (the reference writes indent=2 and random ids).                                                      */
 int cv_write_geojson(const char* path, int polygons, int n, const double* centroid, const int64_t* ct_off, const int64_t* ct_xy,
                      const int32_t* type, int n_feat, const int32_t* feat_type, const char* const* feat_head, const char* const* feat_tail);
+
+/* Streaming slide tail (round 5; the reference's writers run after the whole tile loop, cell_detection.py:423-475).
+ * cv_render_cells: the cells of ONE finished batch rendered once, one JSON object per cell (the text cv_write_cells_json emits between its
+ *   ",\n" separators), into an opaque buffer with per-cell offsets; arguments as cv_write_cells_json.  Host code, releases nothing global.
+ * cv_textbuf_compact: the kept cells (keep[k] != 0, NULL = all) of a buffer joined by ",\n" into dst; returns the byte count (also when
+ *   dst is NULL / cap too small: nothing written) — the writer concatenates the batches' chunks in slide order between the file's header
+ *   and footer: byte for byte cv_write_cells_json of the kept cells.
+ * cv_write_rows: kept rows (row_bytes each) of n_chunks host arrays, in order, written at file_offset of an existing file with pwrite on
+ *   several threads; *crc_out = CRC-32 (zip) of the bytes, *rows_out = rows written.  Fills the tensor holes of a cells.pt archive that
+ *   torch.save wrote under torch.serialization.skip_data.                                                                              */
+typedef struct cv_textbuf cv_textbuf;
+int cv_render_cells(int detection_only, int n, const int64_t* bbox, const double* centroid, const int64_t* ct_off, const int64_t* ct_xy,
+                    const double* type_prob, const int32_t* type, const int32_t* patch_rc, const int32_t* status,
+                    const int64_t* offset_global, const uint8_t* edge, const uint8_t* edge_pos, cv_textbuf** out);
+int64_t cv_textbuf_compact(const cv_textbuf* b, const uint8_t* keep, char* dst, int64_t cap);
+void cv_textbuf_free(cv_textbuf* b);
+int cv_write_rows(const char* path, int64_t file_offset, int64_t row_bytes, int n_chunks, const void* const* chunk_ptr,
+                  const int64_t* chunk_rows, const uint8_t* const* keep, uint32_t* crc_out, int64_t* rows_out);
 /* Cell-token pooling of the inference CLI (cell_detection.py:396-409) on the device record arrays of cv_pp_run:
  * out[rec_offset[b] + i, :] = mean over tokens_nhwc[b, floor(rmin/p):ceil(rmax/p), floor(cmin/p):ceil(cmax/p), :] for
  * record i < n_recs[b] (indices cast to uint8 as the reference does).  rec_offset: int64 [B] device (exclusive prefix

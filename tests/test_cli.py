@@ -579,3 +579,109 @@ def test_cli_route_with_real_cells_against_the_oracle(tmp_path):
     assert all(torch.equal(a, torch.Tensor(c["contour"])) for a, c in zip(g.contours[:50], cells["cells"][:50]))
     print(f"\n[cli] {k} cells from 4 tiles == oracle; {len(want_dicts)} kept after the global stitch; tile loop "
           f"{stats['tiles'] / stats['t_loop']:.1f} tiles/s (stand-in forward)")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# streaming slide tail (cellvit_amd/inference/tail.py): per-batch rendering / token staging during the loop, chunk assembly at the end
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _feed_tail(tail, tiles, tile_ids, grid, block):
+    """What run_tiles does with a tail: one add_batch per block of `block` consecutive tiles of this rank's shard."""
+    for i in range(0, len(tile_ids), block):
+        ids = tile_ids[i:i + block]
+        sc = _slide_cells_of(tiles, ids, grid=grid)
+        tail.add_batch(ids[0], sc.ir, sc.fr, sc.ct.reshape(-1, 2), sc.tokens)
+
+
+def _streamed_files(outdir, tiles, grid, block, rank=0, world=1, geojson=False):
+    from cellvit_amd import sharding as S
+    from cellvit_amd.inference.tail import SlideTail
+    tail = SlideTail(1024, 1, 64, None, keep_geometry=geojson)
+    _feed_tail(tail, tiles, S.shard_tiles(grid * grid, rank, world, block=block), grid, block)
+    tm: dict = {}
+    job = CD.finish_streamed(tail, torch.device("cpu"), torch.device("cpu"), 1024, 1, 64, geojson, tm)
+    if rank == 0:
+        CD.write_outputs_streamed(outdir, {"magnification": 40, "patch_size": 1024, "downsampling": 1}, ["0_0"], {"Background": 0}, job, geojson, tail)
+    else:
+        tail.close()
+    return tm
+
+
+@pytest.mark.parametrize("block", [2, 4])
+def test_streamed_tail_files_equal_the_batch_route(tmp_path, block):
+    """The streaming slide tail (text rendered per batch, spans of the kept cells joined at the end; cells.pt as a skip_data archive
+    filled by parallel row writes) writes byte-identical JSON documents and a cells.pt that loads to the same container — and whose
+    zip CRC-32 fields are valid — as `finalize_slide` + `write_outputs`."""
+    import zipfile
+    tiles = _synthetic_slide_tiles()
+    ref_all, _ = CD.finalize_slide(_slide_cells_of(tiles, list(range(9))), 1024, 1, 64, want_dicts=False)
+    d1, d2 = tmp_path / "batch", tmp_path / "stream"
+    d1.mkdir(); d2.mkdir()
+    meta = {"magnification": 40, "patch_size": 1024, "downsampling": 1}
+    CD.write_outputs(d1, meta, ["0_0"], {"Background": 0}, ref_all, True, 1024, 1, 64)
+    tm = _streamed_files(d2, tiles, 3, block, geojson=True)
+    assert tm["n_cells_total"] == len(ref_all) and tm["margin_records"] > tm["margin_kept"] > 0
+    for name in ("cells.json", "cell_detection.json"):
+        assert (d1 / name).read_bytes() == (d2 / name).read_bytes(), name
+    from cellvit_amd.datamodel import install_reference_aliases
+    install_reference_aliases()
+    a, b = torch.load(d1 / "cells.pt", weights_only=False), torch.load(d2 / "cells.pt", weights_only=False)
+    assert torch.equal(a.x, b.x) and torch.equal(a.positions, b.positions) and a.metadata == b.metadata
+    assert len(a.contours) == len(b.contours) and all(torch.equal(u, v) for u, v in zip(a.contours, b.contours))
+    assert zipfile.ZipFile(d2 / "cells.pt").testzip() is None          # the CRC-32 fields of the filled records are right
+    for name in ("cells.geojson", "cell_detection.geojson"):           # equal up to the random feature ids
+        ja, jb = json.load(open(d1 / name)), json.load(open(d2 / name))
+        for f in ja + jb:
+            f["id"] = ""
+        assert ja == jb, name
+
+
+def test_streamed_tail_of_an_empty_slide(tmp_path):
+    from cellvit_amd.inference.tail import SlideTail
+    tail = SlideTail(1024, 1, 64, None)
+    job = CD.finish_streamed(tail, torch.device("cpu"), torch.device("cpu"), 1024, 1, 64, False, {})
+    CD.write_outputs_streamed(tmp_path, {"magnification": 40, "patch_size": 1024, "downsampling": 1}, [], {"Background": 0}, job, False, tail)
+    d = json.load(open(tmp_path / "cells.json"))
+    assert d["cells"] == [] and not (tmp_path / "cells.pt").exists()
+
+
+def _streamed_worker(rank, world, port, q, outdir, grid, block):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tiles = _synthetic_slide_tiles(grid=grid)
+    tm = _streamed_files(outdir, tiles, grid, block, rank, world)
+    q.put((rank, tm))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid,block", [(3, 2), (2, 8)])
+def test_world2_streamed_tail_files_are_byte_identical_to_world1(tmp_path, grid, block):
+    """Two ranks (gloo): every rank renders and stages its own batches, only margin records are all-gathered, the kept chunks travel to
+    the writer point to point — the writer's files are byte-identical to the single-process streaming run's (and, by the test above, to
+    the batch route's).  (2, 8): rank 1 receives no tile and still enters every collective."""
+    import socket
+    import torch.multiprocessing as mp
+    tiles = _synthetic_slide_tiles(grid=grid)
+    d1, d2 = tmp_path / "w1", tmp_path / "w2"
+    d1.mkdir(); d2.mkdir()
+    t1 = _streamed_files(d1, tiles, grid, block)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_streamed_worker, args=(r, 2, port, q, d2, grid, block)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, a), (_, b) = res
+    assert a["n_cells_total"] == b["n_cells_total"] == t1["n_cells_total"]
+    assert b["writer_gather_bytes_received"] == 0 and a["writer_gather_bytes_sent"] == 0
+    assert a["writer_gather_bytes_received"] == b["writer_gather_bytes_sent"]
+    for name in ("cells.json", "cell_detection.json", "cells.pt"):
+        assert (d1 / name).read_bytes() == (d2 / name).read_bytes(), name

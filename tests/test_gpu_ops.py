@@ -115,6 +115,13 @@ def test_conv3x3_implicit_gemm_shapes(B, H, W_, C1, C2, Cout, relu):
     _conv3x3_case(F16, B, H, W_, C1, C2, Cout, relu, 0)
 
 
+@pytest.mark.parametrize("B,H,W_,C1,relu", [(2, 128, 128, 64, 1), (3, 256, 512, 64, 1), (1, 200, 300, 32, 1), (2, 144, 112, 32, 0), (1, 131, 260, 64, 0)])
+def test_conv3x3_resident_filter_persistent(B, H, W_, C1, relu):
+    """Cin 32 / 64 -> 64 channels, fp16 out: the persistent kernel with the filter resident in LDS (conv3x3_res_kernel): several tiles per
+    workgroup (768 tiles on 256 CUs), ragged image sides (tiles cut by the right / bottom border), one and two channel chunks."""
+    _conv3x3_case(F16, B, H, W_, C1, 0, 64, relu, 0)
+
+
 def _conv3x3_case(dtype, B, H, W_, C1, C2, Cout, relu, out_f32):
     L, lib = _lib()
     g = torch.Generator().manual_seed(3)

@@ -83,7 +83,7 @@ def build_slide(tmp, tiles, model, with_ckpt=True):
     return os.path.join(tmp, "ckpt.pth"), slide
 
 
-def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batches=2, world_seed=3, real_model=None, slides=1):
+def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batches=2, world_seed=3, real_model=None, slides=1, stream_tail=True):
     """One slide through process_wsi on this process's rank; returns the stats dict of rank 0 (None on other ranks).
     `real_model`: an already built cellvit_amd model (bench.py's); otherwise a seeded checkpoint is written and loaded
     through the CLI's own checkpoint path."""
@@ -115,14 +115,14 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
     inf.run_tiles(wsi, list(range(min(tiles, warmup_batches * batch))), batch)               # warm-up (engine, workspaces)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    stats = inf.process_wsi(wsi, batch_size=batch, geojson=geojson)
+    stats = inf.process_wsi(wsi, batch_size=batch, geojson=geojson, stream_tail=stream_tail)
     total = time.perf_counter() - t0
     dataset = None
     if slides > 1:        # process_dataset mode: the files of slide k are written while the tile loop of slide k+1 runs
         t1 = time.perf_counter()
         loops = []
         for k in range(slides):
-            st = inf.process_wsi(wsi, subdir_name=f"s{k}", batch_size=batch, geojson=geojson, defer_write=True)
+            st = inf.process_wsi(wsi, subdir_name=f"s{k}", batch_size=batch, geojson=geojson, defer_write=True, stream_tail=stream_tail)
             loops.append(st["tiles"] / st["t_loop"])
         inf.wait_for_writers()
         dt = time.perf_counter() - t1
@@ -138,6 +138,7 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
             "exchange_s": stats["exchange_s"], "stitch_s": stats["stitch_s"], "to_dicts_s": stats["to_dicts_s"],
             "margin_bytes_all_gathered": stats.get("margin_bytes_all_gathered"), "writer_gather_bytes_received_rank0": stats.get("writer_gather_bytes_received"),
             "write_s": stats["write_s"], "slide_total_s": total, "slide_tiles_per_s": tiles / total,
+            "tail_s": total - stats["t_loop"], "tail_route": "streamed" if stream_tail else "batch", "tail_wait_workers_s": stats.get("tail_wait_workers_s"),
             "output_MB": out_bytes / 1e6, "host_cpus": os.cpu_count(), "dataset_mode": dataset}
 
 
@@ -150,6 +151,7 @@ def main():
     ap.add_argument("--geojson", action="store_true")
     ap.add_argument("--tmp", default=None)
     ap.add_argument("--slides", type=int, default=1, help="> 1: additionally run that many slides back to back with deferred writers")
+    ap.add_argument("--batch-tail", action="store_true", help="the batch route of the slide tail (finalize_slide + write_outputs) instead of the streaming one")
     args = ap.parse_args()
     if args.ranks > 1 and "WORLD_SIZE" not in os.environ:
         import socket
@@ -167,7 +169,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")                   # all ranks share the box's one GPU: host-side exchange
     torch.cuda.set_device(0)
-    rec = run(args.tiles, args.batch, args.model, args.geojson, args.tmp, slides=args.slides)
+    rec = run(args.tiles, args.batch, args.model, args.geojson, args.tmp, slides=args.slides, stream_tail=not args.batch_tail)
     if rec is not None:
         print(json.dumps(rec))
     if dist.is_initialized():
