@@ -477,6 +477,9 @@ class CellSegmentationInference:
                 finish(pending)
             copy_stream.synchronize()
         stats["t_loop"] = time.perf_counter() - t0
+        if tail is not None:      # the tail holds the batches; the caller only counts the cells
+            ir = np.concatenate([p.ir for p in parts]) if parts else None
+            return SlideCells(ir), processed, stats
         return SlideCells.concat(parts), processed, stats
 
     def wait_for_writers(self) -> None:
@@ -525,10 +528,12 @@ class CellSegmentationInference:
         exch_dev = self.device if (dd and dist.get_backend() == "nccl") else torch.device("cpu")
         mps, mds = wsi.metadata["patch_size"], wsi.metadata["downsampling"]
         tail = None
+        t_enter = time.perf_counter()
         if stream_tail:
             from .tail import SlideTail
             tail = SlideTail(mps, mds, overlap, self.device, keep_geometry=geojson)
         local, processed, stats = self.run_tiles(wsi, my_tiles, batch_size, patch_size, overlap, tail=tail)
+        t_tiles = time.perf_counter()
         self.logger.info(f"[rank {rank}/{world}] {stats['tiles']} tiles in {stats['t_loop']:.2f} s "
                          f"({stats['tiles'] / max(stats['t_loop'], 1e-9):.1f} tiles/s), cells before cleaning: {len(local)}")
         timings: dict = {}
@@ -573,6 +578,8 @@ class CellSegmentationInference:
         elif tail is not None:
             tail.close()
         timings["write_s"] = time.perf_counter() - t0
+        # where the wall time outside the tile loop went: before / after the loop inside run_tiles, agreement + exchange + stitch + gather, writers
+        timings["tail_breakdown_s"] = {"run_tiles_outside_loop": (t_tiles - t_enter) - stats["t_loop"], "finish": t0 - t_tiles, "write": timings["write_s"]}
         stats.update({"n_cells": int(timings.get("n_cells_total", len(allc) if (tail is None and allc is not None) else 0)),
                       "cells_before_cleaning": len(local), "outdir": str(outdir), **timings})
         return stats
@@ -745,7 +752,9 @@ def write_outputs_streamed(outdir: Path, wsi_metadata: dict, processed: List[str
         if errors:
             raise errors[0]
     finally:
-        tail.close()
+        # several GB of host arrays and text: released by a helper thread (munmap of that much takes a few tenths of a second)
+        job.clear()
+        threading.Thread(target=tail.close, name="cellvit-tail-release").start()
 
 
 def pool_cell_tokens_fixed(tokens: torch.Tensor, recs: torch.Tensor, n_recs: torch.Tensor, patch_size: int,

@@ -138,7 +138,7 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
             "exchange_s": stats["exchange_s"], "stitch_s": stats["stitch_s"], "to_dicts_s": stats["to_dicts_s"],
             "margin_bytes_all_gathered": stats.get("margin_bytes_all_gathered"), "writer_gather_bytes_received_rank0": stats.get("writer_gather_bytes_received"),
             "write_s": stats["write_s"], "slide_total_s": total, "slide_tiles_per_s": tiles / total,
-            "tail_s": total - stats["t_loop"], "tail_route": "streamed" if stream_tail else "batch", "tail_wait_workers_s": stats.get("tail_wait_workers_s"),
+            "tail_s": total - stats["t_loop"], "tail_route": "streamed" if stream_tail else "batch", "tail_wait_workers_s": stats.get("tail_wait_workers_s"), "tail_breakdown_s": stats.get("tail_breakdown_s"),
             "output_MB": out_bytes / 1e6, "host_cpus": os.cpu_count(), "dataset_mode": dataset}
 
 
