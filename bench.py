@@ -61,6 +61,9 @@ def parse():
                     help="f8: CDNA4 MX-fp8 MFMA for the encoder's linear layers, fp16 attention core and decoder (BASELINE.json configs[4])")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the short extra legs after the timed region (fp8 engine, CellViT-256, slide-level CLI run)")
+    ap.add_argument("--pp-cu-mask", default="",
+                    help="EXPERIMENT (recorded in config.experiment_env): run the post-processing stream on a CU-masked HIP stream "
+                         "(hipExtStreamCreateWithCUMask); 'N' = N CUs spread evenly over the 256, 'lowN' = the N lowest-numbered CUs")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run post-processing on the forward stream instead of a second HIP stream")
     return ap.parse_args()
@@ -407,6 +410,21 @@ def main():
     overlap = do_pp and not args.no_overlap
     main_stream = torch.cuda.current_stream(dev)
     pp_stream = torch.cuda.Stream(dev) if overlap else main_stream
+    if overlap and args.pp_cu_mask:
+        import ctypes as _C
+        hip = _C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        spec = args.pp_cu_mask
+        n_m = int(spec[3:]) if spec.startswith("low") else int(spec)
+        cus = list(range(n_m)) if spec.startswith("low") else [i * 256 // n_m for i in range(n_m)]
+        words = (_C.c_uint32 * 8)()
+        for c in cus:
+            words[c // 32] |= 1 << (c % 32)
+        sp = _C.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(_C.byref(sp), 8, words)
+        if rc != 0:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+        pp_stream = torch.cuda.ExternalStream(sp.value, device=dev)
+        dbg = dbg + [f"pp_cu_mask={spec}"]
 
     def make_step(nb):
         xb = x[:nb]

@@ -524,6 +524,302 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// attn2d_kernel (round 5): the global blocks of SAM-H at production geometry — fp16, hd 80, 64-wide key grids (BIAS 2), nk a multiple of 64 — with K and
+// V^T tiles staged by LDS-DMA into TWO stages each and ONE barrier per key tile.  attn2_kernel fetches a tile into 24 VGPRs one tile ahead, writes it
+// to LDS between two barriers (nine LDS stores per thread and tile) and needs zero-padded K rows; here
+//   * the K tile is the 64 x 80-half block as it lies in memory (10 one-KiB pieces, rows of 160 B: conflict-free for the fragment reads because the
+//     two 16-byte columns a 16-lane group touches are 16 B apart); the padded contraction slots 80 .. 95 never exist in LDS: lanes g >= 2 of the last
+//     k-step read a 32-byte constant block instead (slots 80 / 81 = 1.0 for the softmax shift, see attn2_kernel's header, the rest zero);
+//   * the V^T tile is 80 rows of 128 B, 16-byte pieces XOR-swizzled by (row >> 1) & 7 at the SOURCE (the DMA's LDS image is lane-linear) so that the
+//     8-byte fragment halves of 16 rows fall on distinct bank groups;
+//   * tile t+1's twenty pieces are issued at the top of tile t, retired by a vmcnt(0) at its end, published by the one barrier.
+// Everything else (transposed flash attention, rel-pos bias from the accumulators' initial value, lazy reference maximum, epilogues) is attn2_kernel's.
+template <int DUMMY = 0>
+__global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
+    using T = half_t;
+    using TR = Traits<half_t>;
+    using Frag = TR::Frag;
+    constexpr int HD = 80, NKS = 3, ND = 5;
+    constexpr int RC2 = 128 + 8;
+    constexpr int KBYTES = KT * HD * 2, VBYTES = HD * KT * 2;           // 10240 each
+    constexpr int STAGE = KBYTES + VBYTES;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // [stage 0: K | V^T][stage 1: K | V^T][constant block 32 B][relcat QT x RC2]
+    T* Cst = reinterpret_cast<T*>(smem_raw + 2 * STAGE);
+    T* Rc = reinterpret_cast<T*>(smem_raw + 2 * STAGE + 32);
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem_raw;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int qblk = lin % gridDim.x;
+    const int q0 = qblk * QT + wave * QW;
+    const int sh = lin / gridDim.x;
+
+    const T* __restrict__ Qg = reinterpret_cast<const T*>(p.Q) + (long)sh * p.L * HD;
+    const T* __restrict__ Kg = reinterpret_cast<const T*>(p.K) + (long)sh * p.L * HD;
+    const T* __restrict__ Vg = reinterpret_cast<const T*>(p.Vt) + (long)sh * HD * p.Lp;
+
+    if (tid < 16) Cst[tid] = (T)((tid < 2) ? 1.f : 0.f);
+    const float c1 = p.scale * LOG2E;
+
+    // ---- DMA of key tile kt into stage st: pieces u = wave + 4 t, t = 0 .. 2 (10 of K, 10 of V^T)
+    auto dma_tile = [&](int kt, int st) {
+        const unsigned char* kb = reinterpret_cast<const unsigned char*>(Kg + (long)kt * KT * HD);
+        const unsigned char* vb = reinterpret_cast<const unsigned char*>(Vg + (long)kt * KT);
+        const unsigned kbl = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)kb);
+        const unsigned kbh = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)kb >> 32));
+        const unsigned vbl = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)vb);
+        const unsigned vbh = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)vb >> 32));
+        const unsigned char* kbase = reinterpret_cast<const unsigned char*>(((unsigned long long)kbh << 32) | kbl);
+        const unsigned char* vbase = reinterpret_cast<const unsigned char*>(((unsigned long long)vbh << 32) | vbl);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int u = wave + 4 * t;
+            if (u < 10) {                                   // wave-uniform
+                const unsigned koff = (unsigned)(u * 1024 + lane * 16);
+                const unsigned kdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)st * STAGE + (unsigned)u * 1024u);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(koff), "s"(kbase), "s"(kdst) : "memory");
+                const int j = u * 64 + lane;                // LDS slot (row d, physical piece c): source piece c ^ ((d >> 1) & 7)
+                const int d = j >> 3, c = (j & 7) ^ ((d >> 1) & 7);
+                const unsigned voff = (unsigned)(d * p.Lp * 2 + c * 16);
+                const unsigned vdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)st * STAGE + (unsigned)KBYTES + (unsigned)u * 1024u);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(vbase), "s"(vdst) : "memory");
+            }
+        }
+    };
+    const int ntiles = p.nk / KT;
+    dma_tile(0, 0);
+
+    // ---- Q fragments, pre-scaled
+    Frag qf[2][NKS];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int row = q0 + qb * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d0 = ks * 32 + g * 8;
+            qf[qb][ks] = (row < p.L && d0 < HD) ? TR::load_frag(Qg + (long)row * HD + d0) : TR::zero_frag();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[qb][ks].v[j] = (half_t)((float)qf[qb][ks].v[j] * c1);
+        }
+    }
+
+    // ---- relcat (BIAS 2), as in attn2_kernel
+    const float inv_scale = 1.0f / p.scale;
+    {
+        T* myrc = Rc + (wave * QW) * RC2;
+        for (int i = lane; i < QW * RC2 / 8; i += 64) store_piece(myrc + i * 8, zero_piece());
+#pragma unroll 1
+        for (int tbl = 0; tbl < 2; ++tbl) {
+            const float* __restrict__ tab = tbl == 0 ? p.tab_h : p.tab_w;
+            const int Ksz = tbl == 0 ? p.KH : p.KW;
+            const int off = tbl == 0 ? 0 : p.KH;
+            const int nj = 2 * Ksz - 1;
+#pragma unroll 1
+            for (int jb = 0; jb * 16 < nj; ++jb) {
+                const int qlo = min(q0, p.L - 1), qhi = min(q0 + QW - 1, p.L - 1);
+                const int clo = tbl == 0 ? qlo / p.KW : qlo % p.KW, chi = tbl == 0 ? qhi / p.KW : (qlo / p.KW == qhi / p.KW ? qhi % p.KW : p.KW - 1);
+                const int cl2 = tbl == 0 ? clo : (qlo / p.KW == qhi / p.KW ? clo : 0);
+                if (jb * 16 + 15 < cl2 || jb * 16 > chi + Ksz - 1) continue;
+                Frag tf[NKS];
+                const int j = jb * 16 + li;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const int d0 = ks * 32 + g * 8;
+                    tf[ks] = TR::zero_frag();
+                    if (j < nj && d0 < HD) {
+                        const float* src = tab + (long)j * HD + d0;
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { tf[ks].v[e] = (half_t)t0[e]; tf[ks].v[4 + e] = (half_t)t1[e]; }
+                    }
+                }
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    f32x4 acc = (f32x4)(0.f);
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) TR::mma(tf[ks], qf[qb][ks], acc);
+                    const int q = q0 + qb * 16 + li;
+                    if (q < p.L) {
+                        const int qy = q / p.KW, qx = q - qy * p.KW;
+                        const int c = tbl == 0 ? qy : qx;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int jj = jb * 16 + g * 4 + r;
+                            const int kk = c - jj + Ksz - 1;
+                            if (jj < nj && kk >= 0 && kk < Ksz) myrc[(qb * 16 + li) * RC2 + off + kk] = (half_t)(acc[r] * inv_scale);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // tile 0, the constant block and this wave's relcat rows are in place
+
+    float bw[2][4][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bw[qb][kb][r] = (float)Rc[(wave * QW + qb * 16 + li) * RC2 + p.KH + kb * 16 + g * 4 + r];
+
+    f32x4 o[2][ND];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int n = 0; n < ND; ++n) o[qb][n] = (f32x4)(0.f);
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    const bool wave_active = q0 < p.L;
+
+    // fragment addresses (bytes, relative to a stage): K rows li of key block kb at kb * 16 * 160; lanes g >= 2 of the last k-step read the constant block
+    const unsigned krow = (unsigned)(li * HD * 2);
+    const bool pad_lane = g >= 2;
+    const unsigned k2_base = pad_lane ? (unsigned)(2 * STAGE) + (unsigned)(g - 2) * 16u : krow + (unsigned)(64 + g * 8) * 2u;
+    const unsigned k2_kb = pad_lane ? 0u : (unsigned)(16 * HD * 2);
+    const unsigned k2_st = pad_lane ? 0u : (unsigned)STAGE;
+    // V^T rows n * 16 + li: physical piece = logical ^ ((row >> 1) & 7); logical piece of (m, half h) = 4 m + 2 h + (g >> 1), byte (g & 1) * 8 inside
+    unsigned vsw[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) vsw[n] = (unsigned)(((n * 16 + li) >> 1) & 7);
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < ntiles) dma_tile(kt + 1, st ^ 1);     // (every wave is past the barrier that ended tile kt - 1: that stage is free)
+        if (wave_active) {
+            const unsigned char* sK = smem_raw + st * STAGE;
+            const unsigned char* sV = sK + KBYTES;
+            float shift[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float bh = (float)Rc[(wave * QW + qb * 16 + li) * RC2 + kt];       // kh == kt
+                shift[qb] = bh - m_run[qb];
+                const half_t hi = (half_t)shift[qb];
+                const half_t lo = (half_t)(shift[qb] - (float)hi);
+                qf[qb][NKS - 1].v[0] = g == 2 ? hi : qf[qb][NKS - 1].v[0];
+                qf[qb][NKS - 1].v[1] = g == 2 ? lo : qf[qb][NKS - 1].v[1];
+            }
+            f32x4 s[2][4];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[qb][kb][r] = bw[qb][kb][r];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    Frag kf;
+                    if (ks < NKS - 1) kf = TR::load_frag(reinterpret_cast<const T*>(sK + krow + kb * (16 * HD * 2) + (ks * 32 + g * 8) * 2));
+                    else kf = TR::load_frag(reinterpret_cast<const T*>(smem_raw + k2_base + (unsigned)st * k2_st + (unsigned)kb * k2_kb));
+                    TR::mma(kf, qf[0][ks], s[0][kb]);
+                    TR::mma(kf, qf[1][ks], s[1][kb]);
+                }
+            }
+            constexpr float LAZY_TAU = 8.0f;
+            Frag pf[2][2];
+            float tmax[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float mx = __builtin_fmaxf(__builtin_fmaxf(s[qb][0][0], s[qb][0][1]), s[qb][0][2]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][0][3]), s[qb][1][0]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][1][1]), s[qb][1][2]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][1][3]), s[qb][2][0]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][2][1]), s[qb][2][2]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][2][3]), s[qb][3][0]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][3][1]), s[qb][3][2]);
+                tmax[qb] = __builtin_fmaxf(mx, s[qb][3][3]);
+            }
+            if (kt == 0 || __any((tmax[0] > LAZY_TAU) || (tmax[1] > LAZY_TAU))) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    float mx = tmax[qb];
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    m_run[qb] += delta;
+                    l_run[qb] *= alpha;
+#pragma unroll
+                    for (int n = 0; n < ND; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[qb][n][r] *= alpha;
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[qb][kb][r] -= delta;
+                }
+            }
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float rs = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(s[qb][kb][r]);
+                        rs += pv;
+                        pf[qb][kb >> 1].v[(kb & 1) * 4 + r] = (half_t)pv;
+                    }
+                l_run[qb] += rs;
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int n = 0; n < ND; ++n) {
+                    const unsigned rowb = (unsigned)((n * 16 + li) * 128) + (unsigned)(g & 1) * 8u;
+                    const unsigned p0 = (unsigned)(4 * m + (g >> 1)) ^ vsw[n], p1 = (unsigned)(4 * m + 2 + (g >> 1)) ^ vsw[n];
+                    const Frag vf = frag_from_2x4<T>(reinterpret_cast<const T*>(sV + rowb + p0 * 16u), reinterpret_cast<const T*>(sV + rowb + p1 * 16u));
+                    TR::mma(vf, pf[0][m], o[0][n]);
+                    TR::mma(vf, pf[1][m], o[1][n]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile kt + 1
+        __syncthreads();
+    }
+
+    const int s_idx = sh / p.heads, h = sh - s_idx * p.heads;
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float lsum = l_run[qb];
+        lsum += __shfl_xor(lsum, 16);
+        lsum += __shfl_xor(lsum, 32);
+        const int qg = q0 + qb * 16 + li;
+        if (qg >= p.L) continue;
+        const long row = (long)s_idx * p.ntok + qg;
+        const float inv = 1.0f / lsum;
+        if (p.out8) { attn_store_mx8(p, o[qb], inv, row, h, g); continue; }
+#pragma unroll
+        for (int n = 0; n < ND; ++n) {
+            Pack4<T>::type v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[qb][n][r] * inv);
+            *reinterpret_cast<Pack4<T>::type*>(out + row * p.D + h * HD + n * 16 + g * 4) = v;
+        }
+    }
+}
+
+int launch_attn2d(const AttnParams& p, hipStream_t stream) {
+    const size_t lds = 2 * (size_t)(KT * 80 * 2 + 80 * KT * 2) + 32 + (size_t)QT * (128 + 8) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2d_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((p.L + QT - 1) / QT, p.S * p.heads);
+    hipLaunchKernelGGL(attn2d_kernel<0>, grid, dim3(NT), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
 template <typename T, int HD, int BIAS, int NBK, int VRM = 0>
 int launch_attn2_impl(const AttnParams& p, hipStream_t stream) {
     constexpr int HDP = (HD + 31) / 32 * 32;
@@ -557,6 +853,12 @@ int launch_attn2_hd(const AttnParams& p, hipStream_t stream) {
         return (int)hipErrorInvalidValue;
     }
     if (!p.tab_h) return launch_attn2_impl<T, HD, 0, 1>(p, stream);
+    if constexpr (sizeof(T) == 2 && HD == 80) {      // production geometry of the SAM-H global blocks: the LDS-DMA kernel (global, unwindowed rows: win == 0)
+        static const int dma_on = cva_env_int("CVA_ATTN2D", 1);
+        if (dma_on && p.KW == KT && p.KH <= 64 && p.nk == p.KH * p.KW && p.nk % KT == 0 && p.L == p.nk && p.win == 0 && (p.Lp % 8) == 0 &&
+            (((size_t)p.K | (size_t)p.Vt) & 15) == 0)
+            return launch_attn2d(p, stream);
+    }
     if (p.KW == KT && p.KH <= 64 && p.nk == p.KH * p.KW) return launch_attn2_impl<T, HD, 2, 1>(p, stream);
     if (p.KH + p.KW <= 32) return launch_attn2_impl<T, HD, 1, 1>(p, stream);
     if (p.KH + p.KW <= 64) return launch_attn2_impl<T, HD, 1, 2>(p, stream);

@@ -691,8 +691,40 @@ __device__ __forceinline__ u64 readlane63(u64 v) {
     return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63) << 32) |
            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
 }
-// wave-wide minimum in VALU data-parallel primitives (6 DPP steps, no LDS round trips)
+// 64-bit steps of the same reduction (round 5): the minimum over the VALUE halves alone costs half the instructions of the 128-bit one, and the
+// value decides almost always — (age, index) only break exact ties of the f64 distance
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void min_step64(u64& k) {
+    const u64 o = dpp_u64<CTRL, ROWMASK>(k);
+    if (o < k) k = o;
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 k) {
+    min_step64<0xb1, 0xf>(k);
+    min_step64<0x4e, 0xf>(k);
+    min_step64<0x114, 0xf>(k);
+    min_step64<0x118, 0xf>(k);
+    min_step64<0x142, 0xa>(k);
+    min_step64<0x143, 0xc>(k);
+    return readlane63(k);
+}
+__device__ __forceinline__ Key2 wave_min_key128(Key2 k);
+// wave-wide minimum of (hi, lo): minimum of hi first; one lane holds it -> its lo; several (an exact tie of values) -> the 128-bit reduction
+// over the tied lanes.  Same result as the 128-bit reduction over all lanes.
 __device__ __forceinline__ Key2 wave_min_key(Key2 k) {
+    const u64 mh = wave_min_u64(k.hi);
+    const u64 tied = __ballot(k.hi == mh);
+    Key2 r;
+    if (__popcll(tied) == 1) {
+        const int w = __ffsll((long long)tied) - 1;
+        r.hi = mh;
+        r.lo = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k.lo >> 32), w) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k.lo, w);
+        return r;
+    }
+    if (k.hi != mh) { k.hi = ~0ull; k.lo = ~0ull; }
+    return wave_min_key128(k);
+}
+// wave-wide minimum in VALU data-parallel primitives (6 DPP steps, no LDS round trips)
+__device__ __forceinline__ Key2 wave_min_key128(Key2 k) {
     min_step<0xb1, 0xf>(k);     // quad_perm [1,0,3,2]
     min_step<0x4e, 0xf>(k);     // quad_perm [2,3,0,1]
     min_step<0x114, 0xf>(k);    // row_shr:4
@@ -713,6 +745,7 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
     __shared__ unsigned s_bits[BITMAP_WORDS];      // claimable (unlabeled mask) pixels of the component's bbox
     const int lane = threadIdx.x;
     const int N = p.H * p.W, W = p.W, H = p.H;
+    const int wshift = (W & (W - 1)) == 0 ? __ffs(W) - 1 : -1;
     {
         const int tile = blockIdx.x;                // tile-interleaved dispatch: wave slot blockIdx.y of every tile before slot + 1 of any
         const long base = (long)tile * N;
@@ -826,7 +859,7 @@ __global__ __launch_bounds__(64) void k_flood(const FloodParams p) {
                 }
                 n = last;
                 // neighbours in skimage order: -W, -1, +1, +W ; claim with a coherent CAS
-                const int py = pidx / W, px = pidx - py * W;
+                const int py = wshift >= 0 ? (pidx >> wshift) : pidx / W, px = pidx - py * W;      // (the division is on the pop's dependency chain)
                 bool have = false; int q = 0; double qv = 0;
                 if (lane < 4) {
                     const int dy = lane == 0 ? -1 : (lane == 3 ? 1 : 0);
