@@ -20,7 +20,8 @@ CLASSES = [  # (key in the json, substring of the kernel name); gemm8_kernel<OMO
     ("mx8", "gemm8_kernel<0, 1, 0, 1, 0>"), ("mx8", "gemm8_kernel<1, 1, 0, 1, 0>"), ("mx8", "gemm8_kernel<3, 1, 0, 1, 0>"),
     ("conv", "gemm8_kernel<0, 1, 0, 0, 1>"),
     ("linear", "gemm8_kernel<0"), ("qkv", "gemm8_kernel<1"), ("convT", "gemm8_kernel<2"), ("conv", "conv3x3_halo_kernel"),
-    ("attn_global", "attn2_kernel"), ("attn_win", "attnwp_kernel"), ("layernorm_mx8", "layernorm_mx8_kernel"),
+    ("conv_halo4", "conv3x3_halo4_kernel"), ("conv_res", "conv3x3_res_kernel"),
+    ("attn_global", "attn2d_kernel"), ("attn_global", "attn2_kernel"), ("attn_win", "attnwp_kernel"), ("layernorm_mx8", "layernorm_mx8_kernel"),
     ("layernorm", "layernorm_kernel"), ("layernorm_add", "layernorm_add_kernel"),
 ]
 BENCH_KEYS = {"linear": "gemm_linear(proj/fc1/fc2/patch/neck)", "qkv": "gemm_qkv", "conv": "conv3x3_implicit_gemm",
