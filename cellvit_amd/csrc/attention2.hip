@@ -527,14 +527,16 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 // attn2d_kernel (round 5): the global blocks of SAM-H at production geometry — fp16, hd 80, 64-wide key grids (BIAS 2), nk a multiple of 64 — with K and
-// V^T tiles staged by LDS-DMA into TWO stages each and ONE barrier per key tile.  attn2_kernel fetches a tile into 24 VGPRs one tile ahead, writes it
+// V^T tiles staged by LDS-DMA through a ring of THREE stages and ONE barrier per key tile.  attn2_kernel fetches a tile into 24 VGPRs one tile ahead, writes it
 // to LDS between two barriers (nine LDS stores per thread and tile) and needs zero-padded K rows; here
 //   * the K tile is the 64 x 80-half block as it lies in memory (10 one-KiB pieces, rows of 160 B: conflict-free for the fragment reads because the
 //     two 16-byte columns a 16-lane group touches are 16 B apart); the padded contraction slots 80 .. 95 never exist in LDS: lanes g >= 2 of the last
 //     k-step read a 32-byte constant block instead (slots 80 / 81 = 1.0 for the softmax shift, see attn2_kernel's header, the rest zero);
 //   * the V^T tile is 80 rows of 128 B, 16-byte pieces XOR-swizzled by (row >> 1) & 7 at the SOURCE (the DMA's LDS image is lane-linear) so that the
 //     8-byte fragment halves of 16 rows fall on distinct bank groups;
-//   * tile t+1's twenty pieces are issued at the top of tile t, retired by a vmcnt(0) at its end, published by the one barrier.
+//   * tile t+2's twenty pieces are issued at the top of tile t; at the end of tile t a COUNTED wait retires tile t+1's (requested a whole tile earlier) and
+//     leaves the newest in flight, then the one barrier publishes them.  Three stages + the kh relcat rows (the kw terms live in registers after the prologue,
+//     their scratch is stage 2) are 78 KB: two workgroups per CU as before.
 // Everything else (transposed flash attention, rel-pos bias from the accumulators' initial value, lazy reference maximum, epilogues) is attn2_kernel's.
 template <int DUMMY = 0>
 __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
@@ -542,14 +544,16 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
     using TR = Traits<half_t>;
     using Frag = TR::Frag;
     constexpr int HD = 80, NKS = 3, ND = 5;
-    constexpr int RC2 = 128 + 8;
+    constexpr int RCK = 64 + 8;                        // relcat row: the kh terms only (the kw terms live in registers after the prologue)
     constexpr int KBYTES = KT * HD * 2, VBYTES = HD * KT * 2;           // 10240 each
     constexpr int STAGE = KBYTES + VBYTES;
+    constexpr int NST = 3;                             // stages: tile t + 2 is requested at the top of tile t
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // [stage 0: K | V^T][stage 1: K | V^T][constant block 32 B][relcat QT x RC2]
-    T* Cst = reinterpret_cast<T*>(smem_raw + 2 * STAGE);
-    T* Rc = reinterpret_cast<T*>(smem_raw + 2 * STAGE + 32);
+    // [stage 0: K | V^T][stage 1][stage 2][constant block 32 B][relcat QT x RCK]; the prologue's kw terms pass through stage 2 (QT x RCK halves)
+    T* Cst = reinterpret_cast<T*>(smem_raw + NST * STAGE);
+    T* Rc = reinterpret_cast<T*>(smem_raw + NST * STAGE + 32);
+    T* Rw = reinterpret_cast<T*>(smem_raw + 2 * STAGE);
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem_raw;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -593,6 +597,7 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
     };
     const int ntiles = p.nk / KT;
     dma_tile(0, 0);
+    if (ntiles > 1) dma_tile(1, 1);
 
     // ---- Q fragments, pre-scaled
     Frag qf[2][NKS];
@@ -611,13 +616,14 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
     // ---- relcat (BIAS 2), as in attn2_kernel
     const float inv_scale = 1.0f / p.scale;
     {
-        T* myrc = Rc + (wave * QW) * RC2;
-        for (int i = lane; i < QW * RC2 / 8; i += 64) store_piece(myrc + i * 8, zero_piece());
+        T* myrc = Rc + (wave * QW) * RCK;
+        T* myrw = Rw + (wave * QW) * RCK;
+        for (int i = lane; i < QW * RCK / 8; i += 64) { store_piece(myrc + i * 8, zero_piece()); store_piece(myrw + i * 8, zero_piece()); }
 #pragma unroll 1
         for (int tbl = 0; tbl < 2; ++tbl) {
             const float* __restrict__ tab = tbl == 0 ? p.tab_h : p.tab_w;
             const int Ksz = tbl == 0 ? p.KH : p.KW;
-            const int off = tbl == 0 ? 0 : p.KH;
+            T* mydst = tbl == 0 ? myrc : myrw;
             const int nj = 2 * Ksz - 1;
 #pragma unroll 1
             for (int jb = 0; jb * 16 < nj; ++jb) {
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
                         for (int r = 0; r < 4; ++r) {
                             const int jj = jb * 16 + g * 4 + r;
                             const int kk = c - jj + Ksz - 1;
-                            if (jj < nj && kk >= 0 && kk < Ksz) myrc[(qb * 16 + li) * RC2 + off + kk] = (half_t)(acc[r] * inv_scale);
+                            if (jj < nj && kk >= 0 && kk < Ksz) mydst[(qb * 16 + li) * RCK + kk] = (half_t)(acc[r] * inv_scale);
                         }
                     }
                 }
@@ -667,7 +673,8 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bw[qb][kb][r] = (float)Rc[(wave * QW + qb * 16 + li) * RC2 + p.KH + kb * 16 + g * 4 + r];
+            for (int r = 0; r < 4; ++r) bw[qb][kb][r] = (float)Rw[(wave * QW + qb * 16 + li) * RCK + kb * 16 + g * 4 + r];
+    __syncthreads();                                    // the kw terms are in registers: stage 2 may take its first tile
 
     f32x4 o[2][ND];
 #pragma unroll
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
     // fragment addresses (bytes, relative to a stage): K rows li of key block kb at kb * 16 * 160; lanes g >= 2 of the last k-step read the constant block
     const unsigned krow = (unsigned)(li * HD * 2);
     const bool pad_lane = g >= 2;
-    const unsigned k2_base = pad_lane ? (unsigned)(2 * STAGE) + (unsigned)(g - 2) * 16u : krow + (unsigned)(64 + g * 8) * 2u;
+    const unsigned k2_base = pad_lane ? (unsigned)(NST * STAGE) + (unsigned)(g - 2) * 16u : krow + (unsigned)(64 + g * 8) * 2u;
     const unsigned k2_kb = pad_lane ? 0u : (unsigned)(16 * HD * 2);
     const unsigned k2_st = pad_lane ? 0u : (unsigned)STAGE;
     // V^T rows n * 16 + li: physical piece = logical ^ ((row >> 1) & 7); logical piece of (m, half h) = 4 m + 2 h + (g >> 1), byte (g & 1) * 8 inside
@@ -688,16 +695,17 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
 #pragma unroll
     for (int n = 0; n < ND; ++n) vsw[n] = (unsigned)(((n * 16 + li) >> 1) & 7);
 
+    int st = 0;
     for (int kt = 0; kt < ntiles; ++kt) {
-        const int st = kt & 1;
-        if (kt + 1 < ntiles) dma_tile(kt + 1, st ^ 1);     // (every wave is past the barrier that ended tile kt - 1: that stage is free)
+        const bool ahead = kt + 2 < ntiles;                 // block-uniform
+        if (ahead) dma_tile(kt + 2, st >= 1 ? st - 1 : 2);  // stage (kt + 2) % 3 was read in tile kt - 1: every wave is past the barrier that ended it
         if (wave_active) {
             const unsigned char* sK = smem_raw + st * STAGE;
             const unsigned char* sV = sK + KBYTES;
             float shift[2];
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
-                const float bh = (float)Rc[(wave * QW + qb * 16 + li) * RC2 + kt];       // kh == kt
+                const float bh = (float)Rc[(wave * QW + qb * 16 + li) * RCK + kt];       // kh == kt
                 shift[qb] = bh - m_run[qb];
                 const half_t hi = (half_t)shift[qb];
                 const half_t lo = (half_t)(shift[qb] - (float)hi);
@@ -781,8 +789,12 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile kt + 1
+        // this wave's pieces of tile kt + 1 (requested a tile ago) have landed; those of tile kt + 2, just requested, stay in flight:
+        // six LDS-DMA instructions on waves 0 / 1, four on waves 2 / 3 (LDS-DMA loads retire in order among themselves)
+        if (ahead) { if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        st = st == 2 ? 0 : st + 1;
     }
 
     const int s_idx = sh / p.heads, h = sh - s_idx * p.heads;
@@ -808,7 +820,7 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
 }
 
 int launch_attn2d(const AttnParams& p, hipStream_t stream) {
-    const size_t lds = 2 * (size_t)(KT * 80 * 2 + 80 * KT * 2) + 32 + (size_t)QT * (128 + 8) * 2;
+    const size_t lds = 3 * (size_t)(KT * 80 * 2 + 80 * KT * 2) + 32 + (size_t)QT * (64 + 8) * 2;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2d_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
