@@ -538,7 +538,14 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
 //     leaves the newest in flight, then the one barrier publishes them.  Three stages + the kh relcat rows (the kw terms live in registers after the prologue,
 //     their scratch is stage 2) are 78 KB: two workgroups per CU as before.
 // Everything else (transposed flash attention, rel-pos bias from the accumulators' initial value, lazy reference maximum, epilogues) is attn2_kernel's.
-template <int DUMMY = 0>
+//
+// PIPE = 1 (round 5, second half): the same kernel software-pipelined inside the wave — the S^T MFMAs of key tile t + 1 are issued in the SAME basic block as
+// the exponentials / conversions of tile t and the PV MFMAs of tile t, so that one wave alone keeps the matrix pipe fed while its vector instructions issue
+// (the PIPE = 0 wave runs S^T -> maximum -> exp -> PV strictly in sequence and relies on the SIMD's second wave for all overlap).  K runs two tiles ahead of V:
+// at the top of tile t the pieces of K(t + 3) and V(t + 2) are requested (K(j) and V(j) live in stage j % 3), the counted wait at the end of tile t leaves
+// exactly that batch in flight, so K(t + 2) and V(t + 1) — requested a whole tile earlier — have landed behind the tile's one barrier.  The arithmetic and
+// its order per score are PIPE = 0's: the outputs are bit-identical.
+template <int PIPE = 0>
 __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
     using T = half_t;
     using TR = Traits<half_t>;
@@ -571,6 +578,38 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
     const float c1 = p.scale * LOG2E;
 
     // ---- DMA of key tile kt into stage st: pieces u = wave + 4 t, t = 0 .. 2 (10 of K, 10 of V^T)
+    auto dma_k = [&](int kt, int st) {
+        const unsigned char* kb = reinterpret_cast<const unsigned char*>(Kg + (long)kt * KT * HD);
+        const unsigned kbl = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)kb);
+        const unsigned kbh = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)kb >> 32));
+        const unsigned char* kbase = reinterpret_cast<const unsigned char*>(((unsigned long long)kbh << 32) | kbl);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int u = wave + 4 * t;
+            if (u < 10) {                                   // wave-uniform
+                const unsigned koff = (unsigned)(u * 1024 + lane * 16);
+                const unsigned kdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)st * STAGE + (unsigned)u * 1024u);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(koff), "s"(kbase), "s"(kdst) : "memory");
+            }
+        }
+    };
+    auto dma_v = [&](int kt, int st) {
+        const unsigned char* vb = reinterpret_cast<const unsigned char*>(Vg + (long)kt * KT);
+        const unsigned vbl = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)vb);
+        const unsigned vbh = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)vb >> 32));
+        const unsigned char* vbase = reinterpret_cast<const unsigned char*>(((unsigned long long)vbh << 32) | vbl);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int u = wave + 4 * t;
+            if (u < 10) {
+                const int j = u * 64 + lane;                // LDS slot (row d, physical piece c): source piece c ^ ((d >> 1) & 7)
+                const int d = j >> 3, c = (j & 7) ^ ((d >> 1) & 7);
+                const unsigned voff = (unsigned)(d * p.Lp * 2 + c * 16);
+                const unsigned vdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)st * STAGE + (unsigned)KBYTES + (unsigned)u * 1024u);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(vbase), "s"(vdst) : "memory");
+            }
+        }
+    };
     auto dma_tile = [&](int kt, int st) {
         const unsigned char* kb = reinterpret_cast<const unsigned char*>(Kg + (long)kt * KT * HD);
         const unsigned char* vb = reinterpret_cast<const unsigned char*>(Vg + (long)kt * KT);
@@ -675,6 +714,7 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) bw[qb][kb][r] = (float)Rw[(wave * QW + qb * 16 + li) * RCK + kb * 16 + g * 4 + r];
     __syncthreads();                                    // the kw terms are in registers: stage 2 may take its first tile
+    if constexpr (PIPE) { if (ntiles > 2) dma_k(2, 2); }
 
     f32x4 o[2][ND];
 #pragma unroll
@@ -695,6 +735,180 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
 #pragma unroll
     for (int n = 0; n < ND; ++n) vsw[n] = (unsigned)(((n * 16 + li) >> 1) & 7);
 
+    if constexpr (PIPE) {
+        constexpr float LAZY_TAU = 8.0f;
+        // S^T of key tile ktn (its K image in stage stn) into sn: the shift rides in the spare contraction slots, the kw terms are the initial value
+        auto score = [&](int ktn, int stn, f32x4 (&sn)[2][4]) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float bh = (float)Rc[(wave * QW + qb * 16 + li) * RCK + ktn];      // kh == key tile
+                const float shift = bh - m_run[qb];
+                const half_t hi = (half_t)shift;
+                const half_t lo = (half_t)(shift - (float)hi);
+                qf[qb][NKS - 1].v[0] = g == 2 ? hi : qf[qb][NKS - 1].v[0];
+                qf[qb][NKS - 1].v[1] = g == 2 ? lo : qf[qb][NKS - 1].v[1];
+            }
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sn[qb][kb][r] = bw[qb][kb][r];
+            const unsigned char* sK = smem_raw + stn * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    Frag kf;
+                    if (ks < NKS - 1) kf = TR::load_frag(reinterpret_cast<const T*>(sK + krow + kb * (16 * HD * 2) + (ks * 32 + g * 8) * 2));
+                    else kf = TR::load_frag(reinterpret_cast<const T*>(smem_raw + k2_base + (unsigned)stn * k2_st + (unsigned)kb * k2_kb));
+                    TR::mma(kf, qf[0][ks], sn[0][kb]);
+                    TR::mma(kf, qf[1][ks], sn[1][kb]);
+                }
+            }
+        };
+        // the 16-score maximum of one query block's tile (v_max3 chain)
+        auto tile_max = [&](const f32x4 (&sx)[4]) {
+            float mx = __builtin_fmaxf(__builtin_fmaxf(sx[0][0], sx[0][1]), sx[0][2]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, sx[0][3]), sx[1][0]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, sx[1][1]), sx[1][2]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, sx[1][3]), sx[2][0]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, sx[2][1]), sx[2][2]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, sx[2][3]), sx[3][0]);
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, sx[3][1]), sx[3][2]);
+            return __builtin_fmaxf(mx, sx[3][3]);
+        };
+        float tm[2] = {0.f, 0.f};                               // maxima of the scores in sc (computed at the end of the tile that produced them)
+        // One key tile.  [A] the lazy-maximum test of sc (rare: raise the reference), then ONE stretch of 44 MFMAs in 22 steps, each step fenced so that the
+        // issue order is the source order: S^T(kt + 1) -> sn in 12 steps (K fragment of the next step prefetched; the shift pair, then the exponentials /
+        // row sums / conversions of sc's key blocks 0, 1 ride beside them), PV(kt) part m = 0 in 5 steps (beside them: key blocks 2, 3), part m = 1 in 5 steps
+        // (beside them: the maxima of sn for the next tile's test).
+        auto tile = [&](auto last_tag, int kt, int st, f32x4 (&sc)[2][4], f32x4 (&sn)[2][4]) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            const bool k3 = kt + 3 < ntiles, v2 = kt + 2 < ntiles;                      // block-uniform
+            if (k3) dma_k(kt + 3, st);                         // K(kt) was read in tile kt - 1, V(kt - 1) too: every wave is past the barrier that ended it
+            if (v2) dma_v(kt + 2, st >= 1 ? st - 1 : 2);
+            if (wave_active) {
+                if (kt == 0 || __any((tm[0] > LAZY_TAU) || (tm[1] > LAZY_TAU))) {
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        float mx = tm[qb];
+                        mx = fmaxf(mx, __shfl_xor(mx, 16));
+                        mx = fmaxf(mx, __shfl_xor(mx, 32));
+                        const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+                        m_run[qb] += delta;
+                        l_run[qb] *= alpha;
+#pragma unroll
+                        for (int n = 0; n < ND; ++n)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[qb][n][r] *= alpha;
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sc[qb][kb][r] -= delta;
+                    }
+                }
+                Frag pf[2][2];
+                float rs[2] = {0.f, 0.f};
+                auto soft4 = [&](int qb, int kb) {             // four scores of sc: exp2, row sum, fp16 P^T slots
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(sc[qb][kb][r]);
+                        rs[qb] += pv;
+                        pf[qb][kb >> 1].v[(kb & 1) * 4 + r] = (half_t)pv;
+                    }
+                };
+                const unsigned char* sV = smem_raw + st * STAGE + KBYTES;
+                auto v_frag = [&](int m, int n) {
+                    const unsigned rowb = (unsigned)((n * 16 + li) * 128) + (unsigned)(g & 1) * 8u;
+                    const unsigned p0 = (unsigned)(4 * m + (g >> 1)) ^ vsw[n], p1 = (unsigned)(4 * m + 2 + (g >> 1)) ^ vsw[n];
+                    return frag_from_2x4<T>(reinterpret_cast<const T*>(sV + rowb + p0 * 16u), reinterpret_cast<const T*>(sV + rowb + p1 * 16u));
+                };
+                Frag vf = v_frag(0, 0);
+                if constexpr (!LAST) {
+                    const int stn = st == 2 ? 0 : st + 1;
+                    const unsigned char* sK = smem_raw + stn * STAGE;
+                    auto k_frag = [&](int ks, int kb) {
+                        if (ks < NKS - 1) return TR::load_frag(reinterpret_cast<const T*>(sK + krow + kb * (16 * HD * 2) + (ks * 32 + g * 8) * 2));
+                        return TR::load_frag(reinterpret_cast<const T*>(smem_raw + k2_base + (unsigned)stn * k2_st + (unsigned)kb * k2_kb));
+                    };
+                    Frag kf = k_frag(0, 0);
+                    float bh[2];
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) bh[qb] = (float)Rc[(wave * QW + qb * 16 + li) * RCK + kt + 1];      // kh == key tile
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) {
+                        const int ks = j >> 2, kb = j & 3;
+                        Frag kn = kf;
+                        if (j + 1 < 12) kn = k_frag((j + 1) >> 2, (j + 1) & 3);
+                        if (ks == 0) {                          // the accumulators start from the kw terms
+#pragma unroll
+                            for (int qb = 0; qb < 2; ++qb) {
+                                f32x4 c0;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) c0[r] = bw[qb][kb][r];
+                                TR::mma(kf, qf[qb][0], c0);
+                                sn[qb][kb] = c0;
+                            }
+                        } else {
+                            TR::mma(kf, qf[0][ks], sn[0][kb]);
+                            TR::mma(kf, qf[1][ks], sn[1][kb]);
+                        }
+                        if (j == 0 || j == 1) {                 // the shift of tile kt + 1 into the spare contraction slots (read by the steps of ks = 2)
+                            const int qb = j;
+                            const float shift = bh[qb] - m_run[qb];
+                            const half_t hi = (half_t)shift;
+                            const half_t lo = (half_t)(shift - (float)hi);
+                            qf[qb][NKS - 1].v[0] = g == 2 ? hi : qf[qb][NKS - 1].v[0];
+                            qf[qb][NKS - 1].v[1] = g == 2 ? lo : qf[qb][NKS - 1].v[1];
+                        }
+                        if (j >= 2 && j < 10 && (j & 1) == 0) soft4((j - 2) >> 2, ((j - 2) >> 1) & 1);      // j = 2, 4, 6, 8: (qb 0, kb 0), (0, 1), (1, 0), (1, 1)
+                        kf = kn;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    soft4(0, 0); soft4(0, 1); soft4(1, 0); soft4(1, 1);
+                }
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const int m = j / 5, n = j - m * 5;
+                    Frag vn = vf;
+                    if (j + 1 < 10) vn = v_frag((j + 1) / 5, (j + 1) % 5);
+                    TR::mma(vf, pf[0][m], o[0][n]);
+                    TR::mma(vf, pf[1][m], o[1][n]);
+                    if (j < 4) soft4(j >> 1, 2 + (j & 1));      // key blocks 2, 3 (P^T part m = 1)
+                    if constexpr (!LAST) { if (j == 6 || j == 8) tm[(j - 6) >> 1] = tile_max(sn[(j - 6) >> 1]); }
+                    vf = vn;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                l_run[0] += rs[0];
+                l_run[1] += rs[1];
+            }
+            // K(kt + 2) and V(kt + 1), requested a tile ago, have landed; this tile's requests stay in flight (three pieces each on waves 0 / 1, two on waves 2 / 3)
+            if (k3) { if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else if (v2) { if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        f32x4 sa[2][4], sb[2][4];
+        if (wave_active) { score(0, 0, sa); tm[0] = tile_max(sa[0]); tm[1] = tile_max(sa[1]); }
+        int st = 0, kt = 0;
+        for (; kt + 2 < ntiles; kt += 2) {                  // two tiles per trip: the score registers alternate, no copies
+            tile(std::false_type{}, kt, st, sa, sb);
+            st = st == 2 ? 0 : st + 1;
+            tile(std::false_type{}, kt + 1, st, sb, sa);
+            st = st == 2 ? 0 : st + 1;
+        }
+        if (kt + 2 == ntiles) {
+            tile(std::false_type{}, kt, st, sa, sb);
+            st = st == 2 ? 0 : st + 1;
+            tile(std::true_type{}, kt + 1, st, sb, sa);
+        } else {
+            tile(std::true_type{}, kt, st, sa, sb);
+        }
+    } else {
     int st = 0;
     for (int kt = 0; kt < ntiles; ++kt) {
         const bool ahead = kt + 2 < ntiles;                 // block-uniform
@@ -797,6 +1011,8 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
         st = st == 2 ? 0 : st + 1;
     }
 
+    }
+
     const int s_idx = sh / p.heads, h = sh - s_idx * p.heads;
     T* __restrict__ out = reinterpret_cast<T*>(p.out);
 #pragma unroll
@@ -819,16 +1035,18 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
     }
 }
 
-int launch_attn2d(const AttnParams& p, hipStream_t stream) {
+int launch_attn2d(const AttnParams& p, hipStream_t stream, int pipe) {
     const size_t lds = 3 * (size_t)(KT * 80 * 2 + 80 * KT * 2) + 32 + (size_t)QT * (64 + 8) * 2;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2d_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2d_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((p.L + QT - 1) / QT, p.S * p.heads);
-    hipLaunchKernelGGL(attn2d_kernel<0>, grid, dim3(NT), lds, stream, p);
+    if (pipe) hipLaunchKernelGGL(attn2d_kernel<1>, grid, dim3(NT), lds, stream, p);
+    else hipLaunchKernelGGL(attn2d_kernel<0>, grid, dim3(NT), lds, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -866,10 +1084,10 @@ int launch_attn2_hd(const AttnParams& p, hipStream_t stream) {
     }
     if (!p.tab_h) return launch_attn2_impl<T, HD, 0, 1>(p, stream);
     if constexpr (sizeof(T) == 2 && HD == 80) {      // production geometry of the SAM-H global blocks: the LDS-DMA kernel (global, unwindowed rows: win == 0)
-        static const int dma_on = cva_env_int("CVA_ATTN2D", 1);
+        static const int dma_on = cva_env_int("CVA_ATTN2D", 2);    // 0: attn2_kernel, 1: LDS-DMA ring, 2: + S^T(t + 1) issued beside the softmax of tile t
         if (dma_on && p.KW == KT && p.KH <= 64 && p.nk == p.KH * p.KW && p.nk % KT == 0 && p.L == p.nk && p.win == 0 && (p.Lp % 8) == 0 &&
             (((size_t)p.K | (size_t)p.Vt) & 15) == 0)
-            return launch_attn2d(p, stream);
+            return launch_attn2d(p, stream, dma_on >= 2);
     }
     if (p.KW == KT && p.KH <= 64 && p.nk == p.KH * p.KW) return launch_attn2_impl<T, HD, 2, 1>(p, stream);
     if (p.KH + p.KW <= 32) return launch_attn2_impl<T, HD, 1, 1>(p, stream);
