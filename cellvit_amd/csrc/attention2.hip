@@ -545,7 +545,9 @@ __global__ __launch_bounds__(NT, 2) void attn2_kernel(const AttnParams p) {
 // at the top of tile t the pieces of K(t + 3) and V(t + 2) are requested (K(j) and V(j) live in stage j % 3), the counted wait at the end of tile t leaves
 // exactly that batch in flight, so K(t + 2) and V(t + 1) — requested a whole tile earlier — have landed behind the tile's one barrier.  The arithmetic and
 // its order per score are PIPE = 0's: the outputs are bit-identical.
-template <int PIPE = 0>
+// DBG (ablation library only, CVA_ATTN2D_DBG; results are wrong by construction): 1 exponentials -> multiplies, 2 no S^T MFMAs, 4 no PV MFMAs, 8 no per-tile wait /
+// barrier, 16 K fragments not re-read, 32 V^T fragments not re-read, 64 no softmax arithmetic at all, 128 no tile DMA, 256 one key tile only (prologue + epilogue).
+template <int PIPE = 0, int DBG = 0>
 __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
     using T = half_t;
     using TR = Traits<half_t>;
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
             }
         }
     };
-    const int ntiles = p.nk / KT;
+    const int ntiles = (DBG & 256) ? 1 : p.nk / KT;
     dma_tile(0, 0);
     if (ntiles > 1) dma_tile(1, 1);
 
@@ -652,55 +654,72 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
         }
     }
 
-    // ---- relcat (BIAS 2), as in attn2_kernel
+    // ---- relcat (BIAS 2).  On this path KW == 64 and a wave's 32 queries lie in ONE grid row qy, columns x0 .. x0 + 31 (x0 = 0 | 32), so the table rows a wave
+    // needs are known up front — kh terms: rows qy .. qy + KH - 1 (kh = qy - j + KH - 1), kw terms: rows x0 .. x0 + 94 (kw = qx - j + 63) — ten blocks of 16 rows
+    // (attn2_kernel walks all sixteen blocks of both tables behind divisions by the runtime KW and tests each), and the fragments of block b + 1 are fetched
+    // while block b runs through its MFMAs and stores: measured with the loop cut to one key tile, the prologue was 1.5 ms of the kernel's 7.5
+    // (profiles/r05_m_attn2d_ablation.txt).  Every (query, kh < KH) and (query, kw < 64) entry is written, so the rows need no initialisation.
     const float inv_scale = 1.0f / p.scale;
-    {
+    if (q0 < p.L) {
         T* myrc = Rc + (wave * QW) * RCK;
         T* myrw = Rw + (wave * QW) * RCK;
-        for (int i = lane; i < QW * RCK / 8; i += 64) { store_piece(myrc + i * 8, zero_piece()); store_piece(myrw + i * 8, zero_piece()); }
-#pragma unroll 1
-        for (int tbl = 0; tbl < 2; ++tbl) {
-            const float* __restrict__ tab = tbl == 0 ? p.tab_h : p.tab_w;
-            const int Ksz = tbl == 0 ? p.KH : p.KW;
-            T* mydst = tbl == 0 ? myrc : myrw;
-            const int nj = 2 * Ksz - 1;
-#pragma unroll 1
-            for (int jb = 0; jb * 16 < nj; ++jb) {
-                const int qlo = min(q0, p.L - 1), qhi = min(q0 + QW - 1, p.L - 1);
-                const int clo = tbl == 0 ? qlo / p.KW : qlo % p.KW, chi = tbl == 0 ? qhi / p.KW : (qlo / p.KW == qhi / p.KW ? qhi % p.KW : p.KW - 1);
-                const int cl2 = tbl == 0 ? clo : (qlo / p.KW == qhi / p.KW ? clo : 0);
-                if (jb * 16 + 15 < cl2 || jb * 16 > chi + Ksz - 1) continue;
-                Frag tf[NKS];
-                const int j = jb * 16 + li;
+        const int qy = __builtin_amdgcn_readfirstlane(q0 >> 6), x0 = __builtin_amdgcn_readfirstlane(q0 & 63);
+        const int nbh = (p.KH + 15) >> 4, nblk = nbh + 6;
+        const bool kh4 = (p.KH & 3) == 0;
+        auto load_tab = [&](int blk, Frag (&tf)[NKS]) {
+            const bool hh = blk < nbh;
+            const float* __restrict__ tab = hh ? p.tab_h : p.tab_w;
+            const int nj = hh ? 2 * p.KH - 1 : 2 * KT - 1;
+            const int j = (hh ? qy + 16 * blk : x0 + 16 * (blk - nbh)) + li;
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const int d0 = ks * 32 + g * 8;
-                    tf[ks] = TR::zero_frag();
-                    if (j < nj && d0 < HD) {
-                        const float* src = tab + (long)j * HD + d0;
-                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int d0 = ks * 32 + g * 8;
+                tf[ks] = TR::zero_frag();
+                if (j < nj && d0 < HD) {
+                    const float* src = tab + (long)j * HD + d0;
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { tf[ks].v[e] = (half_t)t0[e]; tf[ks].v[4 + e] = (half_t)t1[e]; }
-                    }
-                }
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    f32x4 acc = (f32x4)(0.f);
-#pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks) TR::mma(tf[ks], qf[qb][ks], acc);
-                    const int q = q0 + qb * 16 + li;
-                    if (q < p.L) {
-                        const int qy = q / p.KW, qx = q - qy * p.KW;
-                        const int c = tbl == 0 ? qy : qx;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int jj = jb * 16 + g * 4 + r;
-                            const int kk = c - jj + Ksz - 1;
-                            if (jj < nj && kk >= 0 && kk < Ksz) mydst[(qb * 16 + li) * RCK + kk] = (half_t)(acc[r] * inv_scale);
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e) { tf[ks].v[e] = (half_t)t0[e]; tf[ks].v[4 + e] = (half_t)t1[e]; }
                 }
             }
+        };
+        auto run_blk = [&](int blk, const Frag (&tf)[NKS]) {
+            const bool hh = blk < nbh;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x4 acc = (f32x4)(0.f);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) TR::mma(tf[ks], qf[qb][ks], acc);
+                if (hh) {                                   // accumulator row 4g + r is table row qy + 16 blk + 4g + r: kh = KH - 1 - 16 blk - 4g - r
+                    const int kh0 = p.KH - 1 - 16 * blk - 4 * g;
+                    T* dst = myrc + (qb * 16 + li) * RCK;
+                    if (kh4 && kh0 >= 3) {                  // four consecutive kh, descending with r: one 8-byte store
+                        Pack4<T>::type v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[3 - r] = (half_t)(acc[r] * inv_scale);
+                        *reinterpret_cast<Pack4<T>::type*>(dst + kh0 - 3) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kh0 - r >= 0) dst[kh0 - r] = (half_t)(acc[r] * inv_scale);
+                    }
+                } else {                                    // table row x0 + 16 b + 4g + r against column x0 + 16 qb + li: kw = 16 (qb - b) + li - 4g - r + 63
+                    const int kw0 = 16 * (qb - (blk - nbh)) + li - 4 * g + KT - 1;
+                    T* dst = myrw + (qb * 16 + li) * RCK;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kw0 - r >= 0 && kw0 - r < KT) dst[kw0 - r] = (half_t)(acc[r] * inv_scale);
+                }
+            }
+        };
+        Frag tfa[NKS], tfb[NKS];
+        load_tab(0, tfa);
+#pragma unroll 1
+        for (int blk = 0; blk < nblk; blk += 2) {
+            if (blk + 1 < nblk) load_tab(blk + 1, tfb);
+            run_blk(blk, tfa);
+            if (blk + 2 < nblk) load_tab(blk + 2, tfa);
+            if (blk + 1 < nblk) run_blk(blk + 1, tfb);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -737,6 +756,7 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
 
     if constexpr (PIPE) {
         constexpr float LAZY_TAU = 8.0f;
+        constexpr int PFD = PIPE == 2 ? 2 : 1;              // LDS fragments are read this many steps ahead of their MFMAs
         // S^T of key tile ktn (its K image in stage stn) into sn: the shift rides in the spare contraction slots, the kw terms are the initial value
         auto score = [&](int ktn, int stn, f32x4 (&sn)[2][4]) {
 #pragma unroll
@@ -781,15 +801,17 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
         float tm[2] = {0.f, 0.f};                               // maxima of the scores in sc (computed at the end of the tile that produced them)
         // One key tile.  [A] the lazy-maximum test of sc (rare: raise the reference), then ONE stretch of 44 MFMAs in 22 steps, each step fenced so that the
         // issue order is the source order: S^T(kt + 1) -> sn in 12 steps (K fragment of the next step prefetched; the shift pair, then the exponentials /
-        // row sums / conversions of sc's key blocks 0, 1 ride beside them), PV(kt) part m = 0 in 5 steps (beside them: key blocks 2, 3), part m = 1 in 5 steps
+        // row sums / conversions of sc's key blocks 0, 1, 2 ride beside them), PV(kt) part m = 0 in 5 steps (beside them: key block 3), part m = 1 in 5 steps
         // (beside them: the maxima of sn for the next tile's test).
         auto tile = [&](auto last_tag, int kt, int st, f32x4 (&sc)[2][4], f32x4 (&sn)[2][4]) {
             constexpr bool LAST = decltype(last_tag)::value;
             const bool k3 = kt + 3 < ntiles, v2 = kt + 2 < ntiles;                      // block-uniform
-            if (k3) dma_k(kt + 3, st);                         // K(kt) was read in tile kt - 1, V(kt - 1) too: every wave is past the barrier that ended it
-            if (v2) dma_v(kt + 2, st >= 1 ? st - 1 : 2);
+            if (!(DBG & 128)) {
+                if (k3) dma_k(kt + 3, st);                     // K(kt) was read in tile kt - 1, V(kt - 1) too: every wave is past the barrier that ended it
+                if (v2) dma_v(kt + 2, st >= 1 ? st - 1 : 2);
+            }
             if (wave_active) {
-                if (kt == 0 || __any((tm[0] > LAZY_TAU) || (tm[1] > LAZY_TAU))) {
+                if (!(DBG & 64) && (kt == 0 || __any((tm[0] > LAZY_TAU) || (tm[1] > LAZY_TAU)))) {
 #pragma unroll
                     for (int qb = 0; qb < 2; ++qb) {
                         float mx = tm[qb];
@@ -811,13 +833,25 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
                 }
                 Frag pf[2][2];
                 float rs[2] = {0.f, 0.f};
+                if constexpr ((DBG & 64) != 0) {
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) pf[qb][m] = qf[qb][m];
+                }
                 auto soft4 = [&](int qb, int kb) {             // four scores of sc: exp2, row sum, fp16 P^T slots
+                    if constexpr ((DBG & 64) != 0) return;
+                    float pv[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(sc[qb][kb][r]);
-                        rs[qb] += pv;
-                        pf[qb][kb >> 1].v[(kb & 1) * 4 + r] = (half_t)pv;
+                        pv[r] = (DBG & 1) ? sc[qb][kb][r] * 0.5f : __builtin_amdgcn_exp2f(sc[qb][kb][r]);
+                        pf[qb][kb >> 1].v[(kb & 1) * 4 + r] = (half_t)pv[r];
                     }
+                    // the row sum as one opaque chain: left to itself the compiler pairs the two query blocks' sums into packed adds at the END of the tile and
+                    // keeps all 32 exponentials live.  The leading s_nop is the wait state a vector instruction needs behind the transcendental that produced its
+                    // operand (the hazard recogniser does not look inside inline assembly).
+                    asm("s_nop 0\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4"
+                        : "+v"(rs[qb]) : "v"(pv[0]), "v"(pv[1]), "v"(pv[2]), "v"(pv[3]));
                 };
                 const unsigned char* sV = smem_raw + st * STAGE + KBYTES;
                 auto v_frag = [&](int m, int n) {
@@ -825,7 +859,10 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
                     const unsigned p0 = (unsigned)(4 * m + (g >> 1)) ^ vsw[n], p1 = (unsigned)(4 * m + 2 + (g >> 1)) ^ vsw[n];
                     return frag_from_2x4<T>(reinterpret_cast<const T*>(sV + rowb + p0 * 16u), reinterpret_cast<const T*>(sV + rowb + p1 * 16u));
                 };
-                Frag vf = v_frag(0, 0);
+                Frag vq[10];
+                vq[0] = v_frag(0, 0);
+                const Frag vf0 = vq[0];
+                if constexpr (LAST && PFD == 2) vq[1] = v_frag(0, 1);
                 if constexpr (!LAST) {
                     const int stn = st == 2 ? 0 : st + 1;
                     const unsigned char* sK = smem_raw + stn * STAGE;
@@ -833,7 +870,10 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
                         if (ks < NKS - 1) return TR::load_frag(reinterpret_cast<const T*>(sK + krow + kb * (16 * HD * 2) + (ks * 32 + g * 8) * 2));
                         return TR::load_frag(reinterpret_cast<const T*>(smem_raw + k2_base + (unsigned)stn * k2_st + (unsigned)kb * k2_kb));
                     };
-                    Frag kf = k_frag(0, 0);
+                    Frag kq[12];
+#pragma unroll
+                    for (int i = 0; i < PFD; ++i) kq[i] = k_frag(i >> 2, i & 3);
+                    const Frag kf0 = kq[0];
                     float bh[2];
 #pragma unroll
                     for (int qb = 0; qb < 2; ++qb) bh[qb] = (float)Rc[(wave * QW + qb * 16 + li) * RCK + kt + 1];      // kh == key tile
@@ -841,9 +881,17 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
 #pragma unroll
                     for (int j = 0; j < 12; ++j) {
                         const int ks = j >> 2, kb = j & 3;
-                        Frag kn = kf;
-                        if (j + 1 < 12) kn = k_frag((j + 1) >> 2, (j + 1) & 3);
-                        if (ks == 0) {                          // the accumulators start from the kw terms
+                        const Frag kf = kq[j];
+                        if (j + PFD < 12) kq[j + PFD] = (DBG & (16 | 2)) ? kf0 : k_frag((j + PFD) >> 2, (j + PFD) & 3);
+                        if (PFD == 2 && j == 10) vq[1] = v_frag(0, 1);
+                        if constexpr ((DBG & 2) != 0) {
+                            if (ks == 0) {
+#pragma unroll
+                                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) sn[qb][kb][r] = bw[qb][kb][r];
+                            }
+                        } else if (ks == 0) {                   // the accumulators start from the kw terms
 #pragma unroll
                             for (int qb = 0; qb < 2; ++qb) {
                                 f32x4 c0;
@@ -864,29 +912,44 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
                             qf[qb][NKS - 1].v[0] = g == 2 ? hi : qf[qb][NKS - 1].v[0];
                             qf[qb][NKS - 1].v[1] = g == 2 ? lo : qf[qb][NKS - 1].v[1];
                         }
-                        if (j >= 2 && j < 10 && (j & 1) == 0) soft4((j - 2) >> 2, ((j - 2) >> 1) & 1);      // j = 2, 4, 6, 8: (qb 0, kb 0), (0, 1), (1, 0), (1, 1)
-                        kf = kn;
+                        // six of the eight softmax pieces ride here (the S^T steps have the MFMA time for them): key blocks 0, 1 (P^T part m = 0), then key block 2
+                        if (j == 2) soft4(0, 0);
+                        if (j == 4) soft4(0, 1);
+                        if (j == 5) soft4(1, 0);
+                        if (j == 7) soft4(1, 1);
+                        if (j == 8) soft4(0, 2);
+                        if (j == 10) soft4(1, 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
-                    soft4(0, 0); soft4(0, 1); soft4(1, 0); soft4(1, 1);
+                    soft4(0, 0); soft4(0, 1); soft4(1, 0); soft4(1, 1); soft4(0, 2); soft4(1, 2);
                 }
 #pragma unroll
                 for (int j = 0; j < 10; ++j) {
                     const int m = j / 5, n = j - m * 5;
-                    Frag vn = vf;
-                    if (j + 1 < 10) vn = v_frag((j + 1) / 5, (j + 1) % 5);
-                    TR::mma(vf, pf[0][m], o[0][n]);
-                    TR::mma(vf, pf[1][m], o[1][n]);
-                    if (j < 4) soft4(j >> 1, 2 + (j & 1));      // key blocks 2, 3 (P^T part m = 1)
-                    if constexpr (!LAST) { if (j == 6 || j == 8) tm[(j - 6) >> 1] = tile_max(sn[(j - 6) >> 1]); }
-                    vf = vn;
+                    const Frag vf = vq[j];
+                    if (j + PFD < 10) vq[j + PFD] = (DBG & (32 | 4)) ? vf0 : v_frag((j + PFD) / 5, (j + PFD) % 5);
+                    if constexpr (!(DBG & 4)) {
+                        TR::mma(vf, pf[0][m], o[0][n]);
+                        TR::mma(vf, pf[1][m], o[1][n]);
+                    } else if (j == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { o[0][0][r] += (float)pf[0][0].v[r] + (float)pf[0][1].v[r]; o[1][0][r] += (float)pf[1][0].v[r] + (float)pf[1][1].v[r]; }
+                    }
+                    if (j == 0) soft4(0, 3);                    // key block 3 (the last of P^T part m = 1)
+                    if (j == 2) soft4(1, 3);
+                    if constexpr (!LAST && !(DBG & 64)) { if (j == 6 || j == 8) tm[(j - 6) >> 1] = tile_max(sn[(j - 6) >> 1]); }
+                    if constexpr (!LAST && (DBG & 64) != 0) { if (j == 6) { o[0][0][0] += sn[0][0][0] + sn[0][1][1] + sn[0][2][2] + sn[0][3][3]; o[1][0][0] += sn[1][0][0] + sn[1][1][1] + sn[1][2][2] + sn[1][3][3]; } }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 l_run[0] += rs[0];
                 l_run[1] += rs[1];
             }
             // K(kt + 2) and V(kt + 1), requested a tile ago, have landed; this tile's requests stay in flight (three pieces each on waves 0 / 1, two on waves 2 / 3)
+            if constexpr ((DBG & 8) != 0) {
+                if (!v2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+                return;
+            }
             if (k3) { if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
             else if (v2) { if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -894,6 +957,7 @@ __global__ __launch_bounds__(NT, 2) void attn2d_kernel(const AttnParams p) {
         };
         f32x4 sa[2][4], sb[2][4];
         if (wave_active) { score(0, 0, sa); tm[0] = tile_max(sa[0]); tm[1] = tile_max(sa[1]); }
+        __syncthreads();                                    // every wave has read K(0): tile 0 re-stages its stage with K(3)
         int st = 0, kt = 0;
         for (; kt + 2 < ntiles; kt += 2) {                  // two tiles per trip: the score registers alternate, no copies
             tile(std::false_type{}, kt, st, sa, sb);
@@ -1040,13 +1104,32 @@ int launch_attn2d(const AttnParams& p, hipStream_t stream, int pipe) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2d_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef CVA_ABLATION
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2d_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2d_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((p.L + QT - 1) / QT, p.S * p.heads);
-    if (pipe) hipLaunchKernelGGL(attn2d_kernel<1>, grid, dim3(NT), lds, stream, p);
-    else hipLaunchKernelGGL(attn2d_kernel<0>, grid, dim3(NT), lds, stream, p);
+#ifdef CVA_ABLATION
+    static const int dbg = cva_env_int("CVA_ATTN2D_DBG", 0);
+    if (pipe == 1 && dbg) {
+        bool hit = false;
+#define CVA_A2D_DBG(D) if (dbg == D) { hit = true; hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2d_kernel<1, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                                       hipLaunchKernelGGL((attn2d_kernel<1, D>), grid, dim3(NT), lds, stream, p); }
+        CVA_A2D_DBG(1) CVA_A2D_DBG(2) CVA_A2D_DBG(4) CVA_A2D_DBG(6) CVA_A2D_DBG(8) CVA_A2D_DBG(48) CVA_A2D_DBG(64) CVA_A2D_DBG(112) CVA_A2D_DBG(128) CVA_A2D_DBG(136) CVA_A2D_DBG(70) CVA_A2D_DBG(198) CVA_A2D_DBG(256)
+#undef CVA_A2D_DBG
+        if (!hit) return (int)hipErrorInvalidValue;
+        return (int)hipGetLastError();
+    }
+#endif
+#ifdef CVA_ABLATION     // the in-wave pipelined variants are experiment instantiations: they need scratch (20 - 30 spilled VGPRs outside the loop), see the header
+    if (pipe == 2) { hipLaunchKernelGGL(attn2d_kernel<2>, grid, dim3(NT), lds, stream, p); return (int)hipGetLastError(); }
+    if (pipe == 1) { hipLaunchKernelGGL(attn2d_kernel<1>, grid, dim3(NT), lds, stream, p); return (int)hipGetLastError(); }
+#endif
+    (void)pipe;
+    hipLaunchKernelGGL(attn2d_kernel<0>, grid, dim3(NT), lds, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -1084,10 +1167,10 @@ int launch_attn2_hd(const AttnParams& p, hipStream_t stream) {
     }
     if (!p.tab_h) return launch_attn2_impl<T, HD, 0, 1>(p, stream);
     if constexpr (sizeof(T) == 2 && HD == 80) {      // production geometry of the SAM-H global blocks: the LDS-DMA kernel (global, unwindowed rows: win == 0)
-        static const int dma_on = cva_env_int("CVA_ATTN2D", 2);    // 0: attn2_kernel, 1: LDS-DMA ring, 2: + S^T(t + 1) issued beside the softmax of tile t
+        static const int dma_on = cva_env_int("CVA_ATTN2D", 1);    // 0: attn2_kernel, 1: LDS-DMA ring; ablation library: 2 = + S^T(t + 1) beside the softmax of tile t, 3 = + deeper fragment prefetch
         if (dma_on && p.KW == KT && p.KH <= 64 && p.nk == p.KH * p.KW && p.nk % KT == 0 && p.L == p.nk && p.win == 0 && (p.Lp % 8) == 0 &&
             (((size_t)p.K | (size_t)p.Vt) & 15) == 0)
-            return launch_attn2d(p, stream, dma_on >= 2);
+            return launch_attn2d(p, stream, dma_on - 1);
     }
     if (p.KW == KT && p.KH <= 64 && p.nk == p.KH * p.KW) return launch_attn2_impl<T, HD, 2, 1>(p, stream);
     if (p.KH + p.KW <= 32) return launch_attn2_impl<T, HD, 1, 1>(p, stream);

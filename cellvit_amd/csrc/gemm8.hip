@@ -19,11 +19,11 @@
 //   phase  MFMA quadrant  operands   reads issued (for the next phase)        DMA issued           counted wait
 //   1      (0,0)          A0, X      Y  <- E.W sub 1
 //   2      (0,1)          A0, Y      A1 <- E.A sub 1
-//   3      (1,1)          A1, Y      -                                        E.W <- tile kt+2     vmcnt(4): O complete
+//   3      (1,1)          A1, Y      - (balanced schedule: first half of A0)  E.W <- tile kt+2     vmcnt(4): O complete
 //   4      (1,0)          A1, X      A0 <- O.A sub 0, Y <- O.W sub 0          E.A <- tile kt+2
 //   5      (0,0)          A0, Y      X  <- O.W sub 1
 //   6      (0,1)          A0, X      A1 <- O.A sub 1
-//   7      (1,1)          A1, X      -                                        O.W <- tile kt+3     vmcnt(4): E complete
+//   7      (1,1)          A1, X      - (balanced schedule: first half of A0)  O.W <- tile kt+3     vmcnt(4): E complete
 //   8      (1,0)          A1, Y      A0 <- E.A sub 0, X <- E.W sub 0          O.A <- tile kt+3
 //
 // (DMA columns of the table: the schedule of the implicit-GEMM convolutions and of the fp8 variant.  The fp16 linear / qkv launches issue the same sixteen pieces
@@ -472,6 +472,21 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         G8_DSR(a[3][0], a_ad0, (BUF) * G8_TILE + (MH) * 8192 + 3 * 2048);                       \
         G8_DSR(a[3][1], a_ad1, (BUF) * G8_TILE + (MH) * 8192 + 3 * 2048);                       \
     } while (0)
+// the two halves of G8_RD_A (fragment rows 0, 1 | 2, 3 of the sub-tile): the balanced schedule reads them in consecutive phases
+#define G8_RD_A_LO(a, BUF, MH)                                                                  \
+    do {                                                                                        \
+        G8_DSR(a[0][0], a_ad0, (BUF) * G8_TILE + (MH) * 8192 + 0 * 2048);                       \
+        G8_DSR(a[0][1], a_ad1, (BUF) * G8_TILE + (MH) * 8192 + 0 * 2048);                       \
+        G8_DSR(a[1][0], a_ad0, (BUF) * G8_TILE + (MH) * 8192 + 1 * 2048);                       \
+        G8_DSR(a[1][1], a_ad1, (BUF) * G8_TILE + (MH) * 8192 + 1 * 2048);                       \
+    } while (0)
+#define G8_RD_A_HI(a, BUF, MH)                                                                  \
+    do {                                                                                        \
+        G8_DSR(a[2][0], a_ad0, (BUF) * G8_TILE + (MH) * 8192 + 2 * 2048);                       \
+        G8_DSR(a[2][1], a_ad1, (BUF) * G8_TILE + (MH) * 8192 + 2 * 2048);                       \
+        G8_DSR(a[3][0], a_ad0, (BUF) * G8_TILE + (MH) * 8192 + 3 * 2048);                       \
+        G8_DSR(a[3][1], a_ad1, (BUF) * G8_TILE + (MH) * 8192 + 3 * 2048);                       \
+    } while (0)
 #define G8_RD_W(b, BUF, NH)                                                                     \
     do {                                                                                        \
         G8_DSR(b[0][0], w_ad0, (BUF) * G8_TILE + (NH) * 4096 + 0 * 2048);                       \
@@ -671,9 +686,13 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
         // waited for one phase before its first read — the wait counts the pieces issued since ("what the last four phases issued may be in flight"):
         //   phase  issues                         (free since)  waits for (read in)     vmcnt |  phase  issues                         waits for (read in)      vmcnt
         //   1      O.A sub 1 <- kt+1 (2)          (8)           E.A sub 1 (2)           8     |  5      E.A sub 1 <- kt+2 (2)          O.A sub 1 (6)            8
-        //   2      E.A sub 0 <- kt+2 (2)          (2)           -                             |  6      O.A sub 0 <- kt+3 (2)          -
-        //   3      E.W sub 0 (2), sub 1 (1)       (2, 3)        O.A, O.W sub 0 (4)      9     |  7      O.W sub 0 (2), sub 1 (1)       E.A, E.W sub 0 (8)       9
+        //   2      E.A sub 0 <- kt+2 (2)          (2)           O.A sub 0 (3, 4)        8     |  6      O.A sub 0 <- kt+3 (2)          E.A sub 0 (7, 8)         8
+        //   3      E.W sub 0 (2), sub 1 (1)       (2, 3)        O.W sub 0 (4)           9     |  7      O.W sub 0 (2), sub 1 (1)       E.W sub 0 (8)            9
         //   4      E.W sub 1 (1)                  (3)           O.W sub 1 (5)           8     |  8      O.W sub 1 (1)                  E.W sub 1 (1)            8
+        // Fragment reads (round 5): phases 4 / 8 used to issue twelve (A0: 8, W: 4) and phases 3 / 7 none — twelve 1-KiB reads of eight waves are 384 cycles of the
+        // LDS's 256 B/clk inside a 512-cycle phase, next to the DMA's writes: 619 core cycles against 540 (profiles/r04_x_gemm8_phase_cycles.txt).  A0's registers are
+        // free from phase 3 on (its MFMAs run in phases 1, 2), so the first half of that read (fragment rows 0, 1) moves to phases 3 / 7: 4 / 8 / 4 / 8 reads per phase;
+        // the sub-tile it reads is retired one phase earlier for that (the waits of phases 2 / 6: two pieces issued since).
         // Measured (profiles/r04_x_gemm8_phase_cycles.txt): with four pieces in each of phases 3, 4, 7, 8 those phases took 700 - 900 core cycles against 520 - 540 for
         // the phases without DMA (2 x 256 matrix-pipe cycles) — sixteen 1-KiB pieces of four waves in one slot are 256 cycles of the CU's 64-B/clk vector-memory path
         // alone; 2 / 2 / 2 / 2: 550 / 655 for phases 3 / 4; 2 / 2 / 3 / 1: 540 / 619.  In the last iteration (nothing left to stage) the waits count down what is in flight.
@@ -689,15 +708,16 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             // ---- phase 2
             G8_PSTAMP(1);
             if (!no_rd) G8_RD_A(A1, 0, 1);
-            if (dm) stage_a(0, kt + 2, 0, 2);
+            if (dm) { stage_a(0, kt + 2, 0, 2); G8_VMCNT(8); } else { G8_VMCNT(6); }      // O.A sub 0 has landed: its first half is read in phase 3
             G8_BAR(); G8_MMQ(8, A0, Y, 0, 1); G8_BAR();
             // ---- phase 3
             G8_PSTAMP(2);
+            if (!no_rd) G8_RD_A_LO(A0, 1, 0);
             if (dm) { stage_w(0, kt + 2, 0, 3); G8_VMCNT(9); } else { G8_VMCNT(4); }
-            G8_BAR(); G8_MMQ(0, A1, Y, 1, 1); G8_BAR();
+            G8_BAR(); G8_MMQ(4, A1, Y, 1, 1); G8_BAR();
             // ---- phase 4
             G8_PSTAMP(3);
-            if (!no_rd) { G8_RD_A(A0, 1, 0); G8_RD_W(Y, 1, 0); }
+            if (!no_rd) { G8_RD_A_HI(A0, 1, 0); G8_RD_W(Y, 1, 0); }
             if (dm) { stage_w(0, kt + 2, 3, 4); G8_VMCNT(8); } else { G8_VMCNT(2); }
             G8_BAR(); G8_MMQ(12, A1, X, 1, 0); G8_BAR();
             // ---- phase 5
@@ -708,15 +728,16 @@ __global__ __launch_bounds__(G8_NT) void gemm8_kernel(const GemmParams p) {
             // ---- phase 6
             G8_PSTAMP(5);
             if (!no_rd) G8_RD_A(A1, 1, 1);
-            if (dm) stage_a(1, kt + 3, 0, 2);
+            if (dm) { stage_a(1, kt + 3, 0, 2); G8_VMCNT(8); }                            // E.A sub 0 (tile kt + 2) has landed: first half read in phase 7
             G8_BAR(); G8_MMQ(8, A0, X, 0, 1); G8_BAR();
             // ---- phase 7
             G8_PSTAMP(6);
+            if (!no_rd) G8_RD_A_LO(A0, 0, 0);               // (after the last tile: a harmless read of stale data)
             if (dm) { stage_w(1, kt + 3, 0, 3); G8_VMCNT(9); }
-            G8_BAR(); G8_MMQ(0, A1, X, 1, 1); G8_BAR();
+            G8_BAR(); G8_MMQ(4, A1, X, 1, 1); G8_BAR();
             // ---- phase 8
             G8_PSTAMP(7);
-            if (!no_rd) { G8_RD_A(A0, 0, 0); G8_RD_W(X, 0, 0); }     // (after the last tile: a harmless read of stale data)
+            if (!no_rd) { G8_RD_A_HI(A0, 0, 0); G8_RD_W(X, 0, 0); }
             if (dm) { stage_w(1, kt + 3, 3, 4); G8_VMCNT(8); }
             G8_BAR(); G8_MMQ(12, A1, Y, 1, 0); G8_BAR();
         }

@@ -112,6 +112,10 @@ def _events(stmts, fp8):
         if m:
             ev.append(("read", m.group(1), int(m.group(2)), int(m.group(3))))
             continue
+        m = re.fullmatch(r"G8_RD_A_(LO|HI)\(\w+, (\d), (\d)\)", s)       # one half of an A sub-tile's fragments: the same sub-tile as far as the rules go
+        if m:
+            ev.append(("read", "A", int(m.group(2)), int(m.group(3))))
+            continue
         m = re.fullmatch(r"G8F_RD_A\(\w+, \w+, (\d), (\d)\)", s)
         if m:
             ev += [("read", "A", int(m.group(1)), int(m.group(2))), ("read", "S", int(m.group(1)), 0)]
@@ -214,7 +218,7 @@ def _replay(fp8, iters, whole=False):
                     expect = buf                                  # before the loop: E = K tile 0
                 else:
                     expect = kt + buf
-                    if not fp8 and buf == 0 and (t % 8) == 7:     # fp16 phase 8: the NEXT iteration's first operands
+                    if not fp8 and buf == 0 and (t % 8) in (6, 7):    # fp16 phases 7 / 8: the NEXT iteration's first operands
                         expect = kt + 2 if kt + 2 < 2 * iters else None
                 read(kind, buf, sub, expect, t)
 
@@ -237,7 +241,7 @@ def test_schedule_is_parsed_completely(fp8):
     assert per_iter == (18 if fp8 else 16)                                     # 2 K tiles x (4 A + 4 W pieces) per wave (+ 2 scale pieces)
     assert max(sum((e[5] - e[4]) if e[0] == "dma" else 1 for e in ph if e[0] in ("dma", "sc")) for ph in per[True]) == 3     # balanced
     reads = sum(1 for ph in per[True] for e in ph if e[0] == "read" and e[1] != "S")
-    assert reads == 8                                                          # every sub-tile of E and O once per iteration
+    assert reads == (8 if fp8 else 10)                                         # every sub-tile of E and O once per iteration (fp16: the A sub-tiles 0 in two halves)
     assert [e for e in top if e[0] == "wait"], "the tile-top wait"
 
 
@@ -258,7 +262,8 @@ def test_hazard_rules_hold_for_the_convolutions_schedule(iters):
 
 @pytest.mark.parametrize("old,new,rule", [
     ("stage_w(0, kt + 2, 0, 3); G8_VMCNT(9);", "stage_w(0, kt + 2, 0, 3); G8_VMCNT(11);", "RAW"),        # a wait loosened by two operations
-    ("if (dm) stage_a(0, kt + 2, 0, 2);", "if (dm) stage_a(0, kt + 2, 2, 4);", "WAR"),                   # E.A sub-tile 1 re-staged in the phase that reads it
+    ("stage_a(0, kt + 2, 0, 2); G8_VMCNT(8);", "stage_a(0, kt + 2, 2, 4); G8_VMCNT(8);", "WAR"),         # E.A sub-tile 1 re-staged in the phase that reads it
+    ("stage_a(1, kt + 3, 0, 2); G8_VMCNT(8);", "stage_a(1, kt + 3, 0, 2); G8_VMCNT(10);", "RAW"),        # the wait in front of the early half-read of E.A loosened
 ])
 def test_the_model_sees_a_broken_schedule(monkeypatch, old, new, rule):
     """Sanity of the checker itself: break the fp16 loop's text and the corresponding rule must trip."""
@@ -283,7 +288,7 @@ def test_the_model_sees_a_broken_schedule(monkeypatch, old, new, rule):
 
 # ------------------------------------------------------------------------------------------------------------------------------------------
 # The counted LDS waits of the fp16 loops: G8_MMQ(n, a, b, ..) = s_waitcnt lgkmcnt(n) in front of the 16 MFMAs on register sets a, b.  LDS reads return in
-# order, so the wait retires everything but the n newest ds_reads: every read INTO a or b must be older than that.  (G8_RD_A = 8 reads, G8_RD_W = 4.)
+# order, so the wait retires everything but the n newest ds_reads: every read INTO a or b must be older than that.  (G8_RD_A = 8 reads, G8_RD_A_LO / _HI and G8_RD_W = 4.)
 def _lds_waits(whole):
     src = _strip(open(SRC).read())
     f8 = _block(src, src.index("if constexpr (F8) {"))
@@ -307,6 +312,11 @@ def test_counted_lds_waits_cover_the_fragments_they_release(whole):
             m = re.fullmatch(r"G8_RD_(A|W)\((\w+), \d, \d\)", st)
             if m:
                 seq += 8 if m.group(1) == "A" else 4
+                last[m.group(2)] = seq
+                continue
+            m = re.fullmatch(r"G8_RD_A_(LO|HI)\((\w+), \d, \d\)", st)
+            if m:
+                seq += 4
                 last[m.group(2)] = seq
                 continue
             m = re.fullmatch(r"G8_MMQ\((\d+), (\w+), (\w+), \d, \d\)", st)

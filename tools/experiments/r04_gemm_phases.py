@@ -24,7 +24,7 @@ t = np.array(buf[:], dtype=np.int64).reshape(8, 2, 24, 8).astype(np.float64)
 ntl = (M // 256) * (N // 256) // 256
 sl = slice(3, min(ntl, 24) - 2)
 d = t[:, :, sl, 1:] - t[:, :, sl, :-1]                 # phases 1 .. 7 (the eighth ends at the next iteration's first stamp, not taken)
-what = ["1: 4 W reads", "2: 8 A reads", "3: W DMA (4 pieces) + vmcnt", "4: 12 reads + A DMA (4 pieces)", "5: 4 W reads", "6: 8 A reads", "7: W DMA (4 pieces) + vmcnt"]
+what = ["1", "2", "3", "4", "5", "6", "7"]      # (what each phase reads / stages: the table at the K loop in gemm8.hip)
 print(f"M={M} N={N} K={K} act={act}: core cycles per phase (top of phase i -> top of phase i+1), mean / min / max over 8 workgroups x 2 wave groups x {sl.stop - sl.start} tiles")
 for i, w in enumerate(what):
     v = d[..., i]
