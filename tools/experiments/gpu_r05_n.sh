@@ -37,7 +37,7 @@ for r in 1 2 3; do
   echo -n "old relcat (r05_i kernel): "; CVA_LIB=libcellvit_amd_prev_attn.so timeout 120 python tools/bench_attn.py 64 64 64 16 1280 0 10 2>&1 | grep -v amdgpu | tail -1 | sed 's/(qkv.*FLOPs/; FLOPs/'
   echo -n "new relcat               : "; timeout 120 python tools/bench_attn.py 64 64 64 16 1280 0 10 2>&1 | grep -v amdgpu | tail -1 | sed 's/(qkv.*FLOPs/; FLOPs/'
 done
-echo -n "ablation library, sequential kernel, one key tile only (prologue + epilogue): "; CVA_LIB=abl CVA_ATTN2D=2 CVA_ATTN2D_DBG=256 timeout 120 python tools/bench_attn.py 64 64 64 16 1280 0 10 2>&1 | grep -v amdgpu | tail -1 | sed 's/(qkv.*FLOPs/; FLOPs/'
+echo -n "ablation library, pipelined kernel with the new prologue, one key tile only (prologue + epilogue): "; CVA_LIB=abl CVA_ATTN2D=2 CVA_ATTN2D_DBG=256 timeout 120 python tools/bench_attn.py 64 64 64 16 1280 0 10 2>&1 | grep -v amdgpu | tail -1 | sed 's/(qkv.*FLOPs/; FLOPs/'
 } | tee $O/attn_prologue_ab.txt
 python - <<'PY'
 import json
