@@ -413,7 +413,9 @@ __device__ __forceinline__ half8_t w_frag_tr_2x4(const half_t* p0, const half_t*
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int HD, int BIAS, int VRM = 0>
+// DBG (ablation library only, CVA_ATTNWP_DBG, VRM = 2; results wrong by construction): 1 no rel-pos phase, 2 no S^T MFMAs / fragment reads, 4 no PV MFMAs / fragment
+// reads, 8 no softmax arithmetic, 16 no K / V DMA, 32 no output stores — what the item's time is made of (profiles/r05_o_attnwp_ablation.txt).
+template <int HD, int BIAS, int VRM = 0, int DBG = 0>
 __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
     static_assert(!VRM || HD == 80, "row-major V: hd 80");
     using GM = AttnwpGeom<HD>;
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
     const float c1 = p.scale * W_LOG2E;
     int it = blockIdx.x;
     int buf = 0;
-    if (it < nitems) { dma_k(it, 0); load_v(it); load_q(it); }
+    if (it < nitems) { if (!(DBG & 16)) dma_k(it, 0); load_v(it); load_q(it); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // zero fill / E / tables / K image 0 complete
 
@@ -588,8 +590,10 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         const int nxt = it + gridDim.x;
         if constexpr (VRM == 2) {
             // (every wave is past the barrier that ended the previous item: the V image and K image buf ^ 1 are free)
-            dma_v(it);                                  // lands during the relcat + S^T phase; published by the barrier behind S^T
-            if (nxt < nitems) dma_k(nxt, buf ^ 1);
+            if (!(DBG & 16)) {
+                dma_v(it);                              // lands during the relcat + S^T phase; published by the barrier behind S^T
+                if (nxt < nitems) dma_k(nxt, buf ^ 1);
+            }
         } else {
             store_v();
             __syncthreads();                            // V^T of this item visible (its K image was fenced by the previous barrier)
@@ -614,7 +618,8 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
             //     values land outside [16, 16 + KW) — inside the row, finite, and E is zero there.  Every position a lane reads back
             //     (16 + 4g + r) is rewritten for every item, so the area needs no initialisation.
             half8_t bf[2];
-            if (BIAS) {
+            if (DBG & 1) { bf[0] = (half8_t)(0); bf[1] = (half8_t)(0); }
+            if (BIAS && !(DBG & 1)) {
                 const float inv_scale = 1.0f / p.scale;
                 half_t* wrows = Wr + (wave * 32) * GM::PWR;
                 half8_t tw[2][NKS];
@@ -658,7 +663,12 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
 #pragma unroll
             for (int kg = 0; kg < WNKB; ++kg) { s[0][kg] = (f32x4)(0.f); s[1][kg] = (f32x4)(0.f); }
             half8_t ring[4];
-            {
+            if constexpr ((DBG & 2) != 0) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[qb][0][r] = (float)bf[qb][r] + (float)qf[qb][0][r];      // (keeps the rel-pos phase and the Q loads alive)
+            } else {
                 const unsigned kbase = ldsK + (unsigned)buf * (GM::KIMG * 2) + (unsigned)(li * PKP + g * 8) * 2u;
                 const unsigned ebase = ldsK + (unsigned)(2 * GM::KIMG + HD * PVF) * 2u + (unsigned)(li * PE1 + g * 8) * 2u;
                 constexpr int TK = NKS * WNKB, TS = TK + (BIAS ? WNKB : 0);
@@ -702,6 +712,17 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                 for (int n = 0; n < ND; ++n) o[qb][n] = (f32x4)(0.f);
             float inv_l[2];
             half8_t pf[2][7];
+            if constexpr ((DBG & 8) != 0) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int kg = 0; kg < WNKB; ++kg) a += s[qb][kg][0] + s[qb][kg][1] + s[qb][kg][2] + s[qb][kg][3];     // (keeps S^T alive)
+                    inv_l[qb] = 1.0f;
+#pragma unroll
+                    for (int m = 0; m < 7; ++m) pf[qb][m] = (half8_t)((half_t)a);
+                }
+            } else
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 // nk > 192 on this path: only the last key block has keys to mask.  p = 2^(s c1 - max c1) as ONE packed fma per
@@ -742,7 +763,14 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                 sum += __shfl_xor(sum, 32);
                 inv_l[qb] = 1.0f / sum;
             }
-            {
+            if constexpr ((DBG & 4) != 0) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int m = 0; m < 7; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[qb][0][r] += (float)pf[qb][m][r] + (float)pf[qb][m][4 + r];           // (keeps the softmax alive)
+            } else {
                 // V^T fragments: key blocks 2m and 2m+1 of row n*16 + li (two 8-byte halves, 32 B apart); block 13 does not
                 // exist (its P is 0): block 12 is read again instead.  Same 4-deep ring as above.
                 constexpr int TP = 7 * ND;
@@ -813,6 +841,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                 if constexpr (HD == 80) {
                     if (p.out8) { attn_store_mx8(p, o[qb], inv_l[qb], row, h, g); continue; }   // fp8 engine: MX-fp8 rows for the proj GEMM
                 }
+                if constexpr ((DBG & 32) != 0) { if (o[qb][0][0] * inv_l[qb] != 12345.f) continue; }
 #pragma unroll
                 for (int n = 0; n < ND; ++n) {
                     half4_t v;
@@ -903,6 +932,17 @@ int launch_attnw_impl(const AttnParams& p, hipStream_t stream) {
                     if (e != hipSuccess) return (int)e;
                     attr_v = true;
                 }
+#ifdef CVA_ABLATION
+                static const int wdbg = cva_env_int("CVA_ATTNWP_DBG", 0);
+                if (wdbg) {
+                    bool hit = false;
+#define CVA_AWP_DBG(D) if (wdbg == D) { hit = true; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attnwp_kernel<HD, BIAS, 2, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                                        hipLaunchKernelGGL((attnwp_kernel<HD, BIAS, 2, D>), dim3(items < n_cu ? items : n_cu), dim3(PNT), ldsp, stream, p); }
+                    CVA_AWP_DBG(1) CVA_AWP_DBG(2) CVA_AWP_DBG(4) CVA_AWP_DBG(6) CVA_AWP_DBG(8) CVA_AWP_DBG(14) CVA_AWP_DBG(15) CVA_AWP_DBG(16) CVA_AWP_DBG(31) CVA_AWP_DBG(32) CVA_AWP_DBG(63)
+#undef CVA_AWP_DBG
+                    return hit ? (int)hipGetLastError() : (int)hipErrorInvalidValue;
+                }
+#endif
                 static const int vreg = cva_env_int("CVA_VRM_REG", 0);      // ablation builds: the register-prefetch form of the V image, for A/B
                 if (CVA_ABLATION_BUILD && vreg)
                     hipLaunchKernelGGL((attnwp_kernel<HD, BIAS, CVA_ABLATION_BUILD ? 1 : 2>), dim3(items < n_cu ? items : n_cu), dim3(PNT), ldsp, stream, p);
