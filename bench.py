@@ -155,16 +155,22 @@ def parity_gates(model, dev):
         x = torch.from_numpy(normalize_tile(synthetic_tile_u8(0, size=256, he_like=False)))[None].to(dev)
         o = model(x, retrieve_tokens=True)
         torch.cuda.synchronize()
+        # the gate is the engine's own documented bound: fp16 = north_star's tolerance; the MX-fp8 engine (BASELINE.json configs[4]) = the bounds its
+        # tests state (tests/test_gpu_fp8.py: block-scaled e4m3 operands in qkv / proj / fc1 / fc2)
+        f8 = "8" in str(model.compute_dtype)
+        tol_abs, tol_mean, tol_arg = (0.25, 0.035, [0.96, 0.945]) if f8 else (1e-2, None, [0.999, 0.998])
         f = {"fixture": "tests/golden/forward_samh_256.npz (imported reference, fp32 CPU)", "engine": model.compute_dtype,
-             "tolerance_max_abs": 1e-2, "tolerance_argmax": [0.999, 0.998]}
+             "tolerance_max_abs": tol_abs, "tolerance_argmax": tol_arg}
+        if tol_mean is not None:
+            f["tolerance_mean_abs"] = tol_mean
         ok = True
         for k in ("nuclei_binary_map", "hv_map", "nuclei_type_map"):
             a = o[k].float().cpu().numpy(); g = gold[k]
             f[k] = {"max_abs": float(np.abs(a - g).max()), "mean_abs": float(np.abs(a - g).mean())}
-            ok = ok and f[k]["max_abs"] < 1e-2
+            ok = ok and f[k]["max_abs"] < tol_abs and (tol_mean is None or f[k]["mean_abs"] < tol_mean)
             if k != "hv_map":
                 f[k]["argmax_agreement"] = float((a.argmax(1) == g.argmax(1)).mean())
-                ok = ok and f[k]["argmax_agreement"] >= (0.999 if k == "nuclei_binary_map" else 0.998)
+                ok = ok and f[k]["argmax_agreement"] >= (tol_arg[0] if k == "nuclei_binary_map" else tol_arg[1])
         f["pass"] = bool(ok)
         out["forward"] = f
     except Exception as e:      # noqa: BLE001
