@@ -46,7 +46,8 @@ __global__ __launch_bounds__(WNT, 2) void attnw_kernel(const AttnParams p) {
     constexpr int PVF = WKEYS + 4;                      // V^T row pitch 424 B = 106 dwords: the 16 rows of a lane group fall on 16 distinct
                                                         // bank pairs under the 32-bank map of ds_read2_b64 (the compiler merges the two 8-byte
                                                         // halves of a fragment read) AND the 64-bank map; rows are 8-byte aligned only
-    constexpr int PE1 = 32 + 8;                         // E / relcat row pitch: 80 B (odd multiple of 16 B: conflict-free b128 reads)
+    constexpr int PE1 = 32 + 8;                         // E / relcat row pitch: 80 B (an odd multiple of 16 B — two-way conflicts for b128 fragment reads
+                                                        // under gfx950's lane grouping, see AttnwpGeom; this kernel serves the non-production shapes)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smemw[];
     half_t* Ks = reinterpret_cast<half_t*>(smemw);      // [64][PK]   (also the staging area of the rel-pos tables)

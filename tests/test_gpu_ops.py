@@ -260,6 +260,7 @@ def _attention_ref(x, Wqkv, bqkv, tab_h, tab_w, B, gh, gw, has_cls, heads, D, wi
     (2, 64, 64, 0, 4, 256, 14, True),    # 1024-px tile window blocks: 64 -> pad 70, 25 windows
     (2, 64, 64, 0, 4, 320, 0, True),     # the same global block, two images
     (1, 32, 64, 0, 4, 320, 0, True),     # key-tile-aligned bias with KH < 64 (2048 keys)
+    (1, 33, 64, 0, 4, 320, 0, True),     # KH not a multiple of 4 (element-wise kh stores of the LDS-DMA kernel's prologue), 2112 queries: the last workgroup half idle
     (1, 64, 64, 1, 6, 384, 0, False),    # ViT-S @1024: 4097 keys (cls token), last key tile holds ONE key, last query block one query
     (1, 20, 20, 0, 4, 320, 0, False),    # hd 80 without bias, 400 keys: ragged last tile (one key block of four)
     (1, 24, 24, 1, 6, 384, 0, False),    # 577 keys: three query blocks of 256, the last with 65 queries
