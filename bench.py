@@ -66,6 +66,13 @@ def parse():
                          "(hipExtStreamCreateWithCUMask); 'N' = N CUs spread evenly over the 256, 'lowN' = the N lowest-numbered CUs")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run post-processing on the forward stream instead of a second HIP stream")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus N > 1.  nccl (= RCCL over xGMI, device exchange buffers) is what the driver's runs use; "
+                         "gloo exists to exercise the multi-rank code path (recorded in config.collective_backend)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="EXPERIMENT (recorded in config.experiment_env): all ranks on cuda:0 — with --backend gloo this runs the N-rank code path, "
+                         "slide leg included, on a 1-GPU box; not a scaling measurement")
+    ap.add_argument("--slide-tiles-per-rank", type=int, default=144, help="tiles per rank of the slide leg (12 x 12 per rank)")
     return ap.parse_args()
 
 
@@ -110,6 +117,11 @@ def cpu_baseline(cfg, sd, tile, cells, with_8_threads=True):
         t8 = time.perf_counter() - t0
         torch.set_num_threads(n_all)
         out["threads8"] = {"value": 1.0 / (t8 + t_pp), "unit": "tiles/s", "cores": 8, "forward_s": t8}
+        out["threads_all"] = {"value": out["value"], "unit": "tiles/s", "cores": n_all, "forward_s": t_fwd}
+        if out["threads8"]["value"] > out["value"]:       # report the BEST thread setting as the baseline (both kept beside it)
+            out.update({"value": out["threads8"]["value"], "cores": 8, "forward_s": t8,
+                        "sample": f"1 tile {tile}x{tile}: oracle forward (torch fp32, best of 8 / {n_all} threads: 8) "
+                                  f"{t8:.2f} s + oracle post-proc (C, 1 thread) {t_pp:.3f} s"})
     # the post-processing "single-threaded (the reference is single-threaded per tile) and x n processes": n worker
     # processes, one tile each, all at once (the reference's DataLoader-style parallelism over tiles)
     try:
@@ -203,7 +215,7 @@ def parity_gates(model, dev):
     return out
 
 
-def extras(model, step, B, dev, make_step=None):
+def extras(model, step, B, dev, make_step=None, slide_tiles=144):
     """Short legs OUTSIDE the timed region, so that the driver's one default line also carries (a) the fp8 engine
     (BASELINE.json configs[4]), (b) CellViT-256 (configs[1] + post-processing) and (c) the slide-level CLI route (configs[3]: PNG
     decode -> forward -> post-processing -> pooling -> records -> exchange -> de-duplication -> writers) with real cell counts.
@@ -312,18 +324,50 @@ def extras(model, step, B, dev, make_step=None):
     except Exception as e:      # noqa: BLE001
         out["vit256_error"] = repr(e)[:200]
     try:
-        spec = importlib.util.spec_from_file_location("bench_slide", os.path.join(ROOT, "tools", "bench_slide.py"))
-        bs = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(bs)
-        r = bs.run(tiles=144, batch=16, model="samh", real_model=model)
-        out["slide"] = {k: r[k] for k in ("tiles", "batch", "ranks", "tile_loop_tiles_per_s_rank0", "cells_written", "margin_records",
-                                          "margin_kept", "exchange_s", "stitch_s", "to_dicts_s", "write_s", "slide_total_s",
-                                          "slide_tiles_per_s", "output_MB", "tail_s", "tail_route")}
-        out["slide_note"] = ("tools/bench_slide.py on a 12 x 12-tile synthetic slide (BASELINE.json configs[3] route on one GPU): the forward runs "
-                             "for real, its planes are replaced by crops of a periodic synthetic nucleus world (~800 cells per tile)")
+        out["slide"] = slide_leg(model, slide_tiles)
+        out["slide_note"] = SLIDE_NOTE
     except Exception as e:      # noqa: BLE001
         out["slide_error"] = repr(e)[:300]
     return out
+
+
+SLIDE_NOTE = ("tools/bench_slide.py on a synthetic pre-patched slide, 144 tiles per rank (BASELINE.json configs[3] route: PNG decode -> forward -> "
+              "post-processing -> pooling -> records -> margin-record all-gatherv -> de-duplication -> writer's gather -> files): the forward runs "
+              "for real, its planes are replaced by crops of a periodic synthetic nucleus world (~800 cells per tile)")
+
+
+def slide_leg(model, tiles, batch=16):
+    """The slide-level route (BASELINE.json configs[3]) on the process group this run initialised: EVERY rank calls this; rank 0 gets the
+    record, the others None.  N ranks: tiles shard block-cyclically (one GPU per rank), margin records travel in ONE all-gatherv, the
+    writer's chunks point to point to rank 0 — over RCCL with device buffers under backend nccl (cell_detection.process_wsi)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_slide", os.path.join(ROOT, "tools", "bench_slide.py"))
+    bs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bs)
+    r = bs.run(tiles=tiles, batch=batch, model="samh", real_model=model)
+    if r is None:
+        return None
+    keys = ("tiles", "batch", "ranks", "collective_backend", "exchange_buffers", "tile_loop_tiles_per_s_rank0", "cells_written", "margin_records",
+            "margin_kept", "exchange_s", "stitch_s", "to_dicts_s", "write_s", "slide_total_s", "slide_tiles_per_s", "output_MB", "tail_s",
+            "tail_route", "margin_bytes_all_gathered", "writer_gather_bytes_received_rank0")
+    return {k: r.get(k) for k in keys}
+
+
+def watchdog(seconds, fn):
+    """Run fn() and os._exit(0) if the main thread has not cancelled the timer within `seconds`: a hung collective in an extra leg must not
+    cost the run its JSON line."""
+    import threading
+
+    def fire():
+        try:
+            fn()
+        finally:
+            sys.stdout.flush()
+            os._exit(0)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def debug_env():
@@ -366,13 +410,25 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
+    dev_index = 0 if args.share_gpu else local_rank
+    if args.share_gpu:
+        if args.backend == "nccl" and world > 1:
+            print("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)", file=sys.stderr)
+            sys.exit(2)
+        dbg = dbg + ["share_gpu"]
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index),
+                                    timeout=datetime.timedelta(minutes=10))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
         if rank == 0:
-            print(f"[bench] {dist.get_world_size()} ranks on backend {dist.get_backend()} (RCCL)", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+            print(f"[bench] {dist.get_world_size()} ranks on backend {dist.get_backend()}" + (" (RCCL)" if args.backend == "nccl" else ""), file=sys.stderr)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    xdev = dev if args.backend == "nccl" else torch.device("cpu")     # where small collective payloads live (gloo: host)
 
     from cellvit_amd import _lib
     from cellvit_amd.model import CellViT256, CellViTSAM
@@ -482,8 +538,7 @@ def main():
 
     eng = model._last_engine
     kernel_events = not args.no_kernel_events
-    if kernel_events:
-        _lib.check(eng.lib.cv_profile_enable(eng.h, 1))
+    # ---- the timed region: K steps, NO per-launch events (the kernel classes are measured in a separate pass below)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -499,13 +554,28 @@ def main():
     # per-rank clocks as well: each rank's own time for its K steps (before the closing barrier), gathered to rank 0
     per_rank_tiles_per_s, backend = [B * args.steps / dt_rank], None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=xdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        own = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(own, torch.tensor([dt_rank], device=dev, dtype=torch.float64))
+        own = [torch.zeros(1, device=xdev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(own, torch.tensor([dt_rank], device=xdev, dtype=torch.float64))
         per_rank_tiles_per_s = [B * args.steps / float(o.item()) for o in own]
         backend = dist.get_backend()
+    # ---- separate profiled pass (rank 0): the same K steps with a HIP event pair around every launch of the engine, on the stream the kernels
+    # run on (cv_profile_enable) — per-class durations and the roofline's live per-launch average
+    prof_steps, prof_ms_per_step = 0, None
+    if kernel_events and rank == 0:
+        _lib.check(eng.lib.cv_profile_enable(eng.h, 1))
+        prof_steps = args.steps
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+        prof_ms_per_step = (time.perf_counter() - tp) / prof_steps * 1e3
+    # ---- N > 1: the slide-level route on THIS process group (every rank enters; rank 0 keeps the record)
+    multi_slide, multi_slide_err = None, None
+    want_slide = world > 1 and not args.no_extras and args.model == "samh" and args.dtype == "f16" and T == 1024
 
     if rank == 0:
         n_inst = int(res[2].sum().item()) if res is not None else 0
@@ -517,7 +587,7 @@ def main():
             _lib.check(eng.lib.cv_profile_enable(eng.h, 0))
             for i, name in enumerate(KCLASS):
                 if n[i]:
-                    kstats[name] = {"launches": int(n[i]), "avg_us": 1e3 * ms[i] / n[i], "total_ms_per_step": ms[i] / args.steps,
+                    kstats[name] = {"launches": int(n[i]), "avg_us": 1e3 * ms[i] / n[i], "total_ms_per_step": ms[i] / prof_steps,
                                     "tflops": fl[i] / (ms[i] * 1e-3) / 1e12, "peak_tflops": KPEAK[i],
                                     "frac": fl[i] / (ms[i] * 1e-3) / 1e12 / KPEAK[i]}
             dom = max(range(NK), key=lambda i: ms[i])
@@ -536,7 +606,9 @@ def main():
             roofline = {"bound": "mfma", "kernel": KCLASS[dom], "achieved": ach, "peak": KPEAK[dom],
                         "unit": "TFLOP/s", "frac": ach / KPEAK[dom],
                         "flops_per_launch": fl[dom] / n[dom], "avg_launch_us": 1e3 * ms[dom] / n[dom],
-                        "launches": int(n[dom]), "traffic": traffic, "traffic_provenance": tprov,
+                        "launches": int(n[dom]), "measured_in": f"separate profiled pass of {prof_steps} steps after the timed region "
+                                                                 f"({prof_ms_per_step:.1f} ms/step with the per-launch events on)",
+                        "traffic": traffic, "traffic_provenance": tprov,
                         "traffic_source": os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, "
                                           "corrected per MI355X_MICROARCH.md (tools/pmc_traffic.py); not collected in this run"
                                           if traffic is not None else None}
@@ -566,14 +638,49 @@ def main():
             "kernel_classes": kstats,
         }
         if world == 1 and not args.no_extras and args.model == "samh" and args.dtype == "f16" and T == 1024:
-            rec["extra"] = extras(model, step, B, dev, make_step)
+            rec["extra"] = extras(model, step, B, dev, make_step, args.slide_tiles_per_rank)
         if world == 1 and args.model == "samh" and T == 1024:
             rec["parity"] = parity_gates(model, dev)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, sd, T, args.cells)
+    else:
+        rec = None
+    if want_slide:
+        # Every rank enters the slide leg.  A watchdog prints the line without it (rank 0) / leaves (others) should a collective hang, and a
+        # launcher's SIGTERM (another rank died) does the same: the scaling line is never hostage to the extra leg.
+        printed = [False]
+
+        def bail(why="slide leg did not finish within 240 s (watchdog)"):
+            if rank == 0 and not printed[0]:
+                printed[0] = True
+                rec["extra"] = {"slide_error": why}
+                print(json.dumps(rec))
+                sys.stdout.flush()
+        import signal
+
+        def on_term(signum, frame):
+            bail("terminated by the launcher during the slide leg (another rank failed)")
+            os._exit(0 if rank == 0 else 1)
+        signal.signal(signal.SIGTERM, on_term)
+        wd = watchdog(240.0, bail)
+        try:
+            multi_slide = slide_leg(model, args.slide_tiles_per_rank * world)
+        except Exception as e:      # noqa: BLE001
+            multi_slide_err = repr(e)[:300]
+        wd.cancel()
+        signal.signal(signal.SIGTERM, signal.SIG_DFL)
+        if rank == 0 and not printed[0]:
+            rec["extra"] = {"slide": multi_slide, "slide_note": SLIDE_NOTE} if multi_slide_err is None else {"slide_error": multi_slide_err}
+            printed[0] = True
+            print(json.dumps(rec))
+            sys.stdout.flush()
+    elif rank == 0:
         print(json.dumps(rec))
+        sys.stdout.flush()
     if world > 1:
+        wd2 = watchdog(60.0, lambda: None)       # a rank that failed above never reaches the group's shutdown: do not wait for it
         dist.destroy_process_group()
+        wd2.cancel()
 
 
 if __name__ == "__main__":

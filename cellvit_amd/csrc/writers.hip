@@ -361,7 +361,11 @@ extern "C" int cv_write_rows(const char* path, int64_t file_offset, int64_t row_
         if (rows_out) *rows_out = total;
         if (crc_out) *crc_out = 0;
         if (total == 0) return CV_OK;
-        const int fd = open(path, O_WRONLY);
+        struct Fd {      // closed on every exit, an allocation failure below included
+            int v;
+            ~Fd() { if (v >= 0) close(v); }
+        } fdg{open(path, O_WRONLY)};
+        const int fd = fdg.v;
         if (fd < 0) { cva_set_error("cv_write_rows: cannot open %s", path); return CV_ERR_INVALID; }
         const int nthr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, (total * row_bytes) / (8 << 20) + 1}));
         std::vector<uint32_t> crcs((size_t)nthr, 0);
@@ -410,7 +414,6 @@ extern "C" int cv_write_rows(const char* path, int64_t file_offset, int64_t row_
         work(0);
         for (int t = started; t < nthr; ++t) work(t);
         for (auto& x : th) x.join();
-        close(fd);
         for (int t = 0; t < nthr; ++t) if (bad[t]) { cva_set_error("cv_write_rows: write to %s failed", path); return CV_ERR_INVALID; }
         if (crc_out) {
             uint32_t crc = crcs[0];

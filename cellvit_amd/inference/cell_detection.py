@@ -531,25 +531,27 @@ class CellSegmentationInference:
         t_enter = time.perf_counter()
         if stream_tail:
             from .tail import SlideTail
-            tail = SlideTail(mps, mds, overlap, self.device, keep_geometry=geojson)
-        local, processed, stats = self.run_tiles(wsi, my_tiles, batch_size, patch_size, overlap, tail=tail)
-        t_tiles = time.perf_counter()
-        self.logger.info(f"[rank {rank}/{world}] {stats['tiles']} tiles in {stats['t_loop']:.2f} s "
-                         f"({stats['tiles'] / max(stats['t_loop'], 1e-9):.1f} tiles/s), cells before cleaning: {len(local)}")
-        timings: dict = {}
-        # a writer failure of the PREVIOUS slide (rank 0 only) is agreed on by all ranks before this slide's first collective:
-        # everyone aborts together instead of the other ranks hanging in the next exchange
-        self._agree_on_writer_error(exch_dev)
-        if tail is None:
-            allc, _ = finalize_slide(local, mps, mds, overlap, device=exch_dev, logger=self.logger, compute_device=self.device,
-                                     timings=timings, want_dicts=False, gather_to=0)
-            job = None
-        else:
-            try:
+            # (remote ranks' geometry is re-gathered as records for the optional geojson pair: only a single-rank run renders it from the tail)
+            tail = SlideTail(mps, mds, overlap, self.device, keep_geometry=geojson and world == 1)
+        try:      # from here to the writer hand-off the tail owns native text buffers and worker threads: release them on ANY exit
+            local, processed, stats = self.run_tiles(wsi, my_tiles, batch_size, patch_size, overlap, tail=tail)
+            t_tiles = time.perf_counter()
+            self.logger.info(f"[rank {rank}/{world}] {stats['tiles']} tiles in {stats['t_loop']:.2f} s "
+                             f"({stats['tiles'] / max(stats['t_loop'], 1e-9):.1f} tiles/s), cells before cleaning: {len(local)}")
+            timings: dict = {}
+            # a writer failure of the PREVIOUS slide (rank 0 only) is agreed on by all ranks before this slide's first collective:
+            # everyone aborts together instead of the other ranks hanging in the next exchange
+            self._agree_on_writer_error(exch_dev)
+            if tail is None:
+                allc, _ = finalize_slide(local, mps, mds, overlap, device=exch_dev, logger=self.logger, compute_device=self.device,
+                                         timings=timings, want_dicts=False, gather_to=0)
+                job = None
+            else:
                 job = self._finish_streamed(tail, exch_dev, mps, mds, overlap, geojson, timings)
-            except BaseException:
+        except BaseException:
+            if tail is not None:
                 tail.close()
-                raise
+            raise
         if world > 1:
             gathered: List[Optional[list]] = [None] * world
             dist.all_gather_object(gathered, processed)       # tile names only (a few bytes per tile)
@@ -619,8 +621,6 @@ def finish_streamed(tail, exch_dev, compute_device, patch_size, downsampling, ov
     if rank == 0:
         job = _merge_shards(shards, D)
         job["n"] = int(n_total)
-        if geojson and world > 1:
-            job["geo"] = None            # (remote ranks keep no f64 geometry: the optional geojson pair is rendered from gathered records)
     if geojson and world > 1:
         mine = SlideCells.concat([SlideCells(b.ir, b.fr, b.ct).select(np.nonzero(b.keep)[0]) for b in tail.batches]) if tail.batches else SlideCells()
         got, s_, r_ = S.gather_records_to(mine.ir, mine.fr, mine.ct, 0, device=exch_dev)

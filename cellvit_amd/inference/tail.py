@@ -115,6 +115,14 @@ class SlideTail:
         b.geo = (g["centroid"], g["ct_off"], g["contour"], typ) if self.keep_geometry else None
 
     def close(self) -> None:
+        # no worker may still be rendering into a batch whose handles are freed below: drop what has not started, wait for what has
+        for b in self.batches:
+            fut = getattr(b, "fut", None)
+            if fut is not None and not fut.cancel():
+                try:
+                    fut.result()
+                except BaseException:      # noqa: BLE001  (the caller is already unwinding, or has seen it via local_margin)
+                    pass
         for b in self.batches:
             for h in (getattr(b, "tb_cells", None), getattr(b, "tb_det", None)):
                 if h:
@@ -229,11 +237,32 @@ def _write_rows(lib, path, offset, row_bytes, chunks):
 def write_cells_pt_streamed(path, n_kept: int, D: int, tok_chunks, pos_chunks, cont_chunks, lens: np.ndarray, metadata: dict) -> str:
     """cells.pt = CellGraphDataWSI(x [n, D], positions [n, 2], metadata, contours = one [len_k, 2] view per cell) (cell_detection.py:469-475),
     written as: torch.save of the container under skip_data (pickle + zip headers, holes for the three storages), the holes filled by
-    cv_write_rows from the chunk lists, the CRC-32 fields patched afterwards.  Falls back to datamodel.save_cell_graph on any surprise."""
+    cv_write_rows from the chunk lists, the CRC-32 fields patched afterwards.  On any surprise (no skip_data in this torch, an archive
+    layout other than the expected one, a short row write) the kept chunks are concatenated and the file is rewritten by the plain
+    torch.save route of datamodel.save_cell_graph — the slide keeps its cells.pt either way."""
+    from ..datamodel import save_cell_graph
+    m = int(lens.sum())
+    try:
+        return _write_cells_pt_holes(path, n_kept, D, tok_chunks, pos_chunks, cont_chunks, lens, metadata, m)
+    except Exception as e:      # noqa: BLE001
+        import logging
+        logging.getLogger("cellvit_amd").warning(f"cells.pt: streamed write failed ({e!r}); rewriting through torch.save")
+
+    def kept(chunks, width):
+        rows = []
+        for a, k in chunks:
+            if a is None or not len(a):
+                continue
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+            rows.append(t if k is None else t[torch.from_numpy(np.ascontiguousarray(k).astype(bool))])
+        return torch.cat(rows).float().reshape(-1, width) if rows else torch.zeros((0, width), dtype=torch.float32)
+    return save_cell_graph(path, kept(tok_chunks, D), kept(pos_chunks, 2), kept(cont_chunks, 2), lens.tolist(), metadata)
+
+
+def _write_cells_pt_holes(path, n_kept, D, tok_chunks, pos_chunks, cont_chunks, lens, metadata, m):
     from torch.serialization import skip_data
     from ..datamodel import save_cell_graph
     lib = _lib.load()
-    m = int(lens.sum())
     with skip_data():
         route = save_cell_graph(path, torch.empty((n_kept, D), dtype=torch.float32), torch.empty((n_kept, 2), dtype=torch.float32),
                                 torch.empty((m, 2), dtype=torch.float32), lens.tolist(), metadata)
@@ -256,9 +285,14 @@ def write_cells_pt_streamed(path, n_kept: int, D: int, tok_chunks, pos_chunks, c
 def write_json_chunks(path, header: bytes, chunks: List[np.ndarray]) -> None:
     """`{header, "cells": [` + the non-empty chunks joined by ",\\n" + `]}` — the document of cv_write_cells_json."""
     nz = [c for c in chunks if len(c)]
-    with open(path, "wb", buffering=0) as f:
+    # buffered writer: BufferedWriter.write() takes all bytes or raises (a raw FileIO write may be short, e.g. before ENOSPC or beyond
+    # 0x7ffff000 bytes per call); the flush inside the with-block surfaces the OS error here, not at garbage collection
+    with open(path, "wb", buffering=1 << 20) as f:
         f.write(b"{" + header + b", \"cells\": [")
         for i, c in enumerate(nz):
             f.write(b"\n" if i == 0 else b",\n")
-            f.write(memoryview(c))
+            mv = memoryview(c).cast("B")
+            for o in range(0, len(mv), 1 << 30):
+                f.write(mv[o:o + (1 << 30)])
         f.write(b"\n]}" if nz else b"]}")
+        f.flush()

@@ -7,9 +7,11 @@ REPLACED by the tile's crop of a periodic synthetic nucleus world (cellvit_amd.s
 neighbouring tiles then see the same nuclei in their overlap, which is what the stitch needs as input.  The forward's cost is
 in the tile loop's time; its outputs are not used.
 
-    python tools/bench_slide.py [--tiles 1024] [--batch 16] [--model samh|vit256] [--ranks 1|2]
-`--ranks 2` runs two processes on the ONE GPU of the box (backend gloo for the exchange): it exercises the sharded route
-(margin-record all-gatherv, replicated stitch, writer's gather), not a scaling claim.
+    python tools/bench_slide.py [--tiles 1024] [--batch 16] [--model samh|vit256] [--ranks N] [--backend nccl|gloo]
+`--ranks N --backend nccl` (the default backend when the box has >= N GPUs): one process per GPU, exchange buffers on the device,
+margin-record all-gatherv and the writer's point-to-point gather over RCCL/xGMI — the configs[3] route as the CLI runs it.
+`--ranks 2 --backend gloo` on a 1-GPU box: two processes share cuda:0 and exchange through host buffers — it exercises the sharded
+route (margin-record all-gatherv, replicated stitch, writer's gather), not a scaling claim.
 Prints one JSON line: tile-loop tiles/s, seconds of exchange / stitch / to_dicts / writers, cell counts.
 """
 import argparse
@@ -93,8 +95,11 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
     from cellvit_amd.synth import synth_world_maps
     rank = dist.get_rank() if dist.is_initialized() else 0
     world_n = dist.get_world_size() if dist.is_initialized() else 1
-    own_tmp = tmp is None
-    if own_tmp:
+    if world_n > 1:       # one slide directory for all ranks: rank 0's choice travels (a launcher gives every rank its own mkdtemp otherwise)
+        box = [tmp if tmp is not None else tempfile.mkdtemp(prefix="cva_slide_")] if rank == 0 else [None]
+        dist.broadcast_object_list(box, src=0)
+        tmp = box[0]
+    elif tmp is None:
         tmp = tempfile.mkdtemp(prefix="cva_slide_")
     if rank == 0:
         build_slide(tmp, tiles, model, with_ckpt=real_model is None)
@@ -132,6 +137,9 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
     if rank != 0:
         return None
     return {"tool": "bench_slide", "model": model, "tiles": tiles, "batch": batch, "ranks": world_n,
+            "collective_backend": dist.get_backend() if dist.is_initialized() else None,
+            "exchange_buffers": ("device" if dist.get_backend() == "nccl" else "host") if dist.is_initialized() else None,
+            "device_of_rank0": torch.cuda.get_device_name(torch.cuda.current_device()) + f" (cuda:{torch.cuda.current_device()})",
             "tile_loop_tiles_per_s_rank0": stats["tiles"] / stats["t_loop"], "tile_loop_s": stats["t_loop"],
             "cells_before_cleaning_rank0": stats["cells_before_cleaning"], "cells_written": stats["n_cells"],
             "margin_records": stats["margin_records"], "margin_kept": stats["margin_kept"],
@@ -148,6 +156,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--model", default="samh", choices=["samh", "vit256"])
     ap.add_argument("--ranks", type=int, default=1)
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="process-group backend for --ranks > 1; default: nccl (RCCL, one GPU per rank) when the box has that many GPUs, else gloo "
+                         "(all ranks on cuda:0, host exchange buffers)")
     ap.add_argument("--geojson", action="store_true")
     ap.add_argument("--tmp", default=None)
     ap.add_argument("--slides", type=int, default=1, help="> 1: additionally run that many slides back to back with deferred writers")
@@ -162,13 +173,21 @@ def main():
         tmp = tempfile.mkdtemp(prefix="cva_slide_")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.ranks}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + ["--tmp", tmp]
-        sys.exit(subprocess.call(cmd))
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
     import torch
     import torch.distributed as dist
-    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = args.backend or ("nccl" if torch.cuda.device_count() >= world else "gloo")
+    local = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0      # nccl: one GPU per rank (RCCL refuses two ranks on one device)
+    torch.cuda.set_device(local)
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")                   # all ranks share the box's one GPU: host-side exchange
-    torch.cuda.set_device(0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")               # all ranks share the box's one GPU: host-side exchange
     rec = run(args.tiles, args.batch, args.model, args.geojson, args.tmp, slides=args.slides, stream_tail=not args.batch_tail)
     if rec is not None:
         print(json.dumps(rec))
