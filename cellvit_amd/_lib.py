@@ -11,10 +11,11 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcellvit_amd.so")
+_EXP_DIR = os.path.join(os.path.dirname(HERE), "build", "experimental")      # experiment libraries never sit in the package
 if os.environ.get("CVA_LIB") == "abl":      # experiment flavour (`python -m cellvit_amd.build --ablation`): the one that honours CVA_* switches
-    LIB_PATH = os.path.join(HERE, "libcellvit_amd_abl.so")
-elif os.environ.get("CVA_LIB", "").endswith(".so"):     # an experiment build of the library under cellvit_amd/ (A/B of compile-time constants)
-    LIB_PATH = os.path.join(HERE, os.path.basename(os.environ["CVA_LIB"]))
+    LIB_PATH = os.path.join(_EXP_DIR, "libcellvit_amd_abl.so")
+elif os.environ.get("CVA_LIB", "").endswith(".so"):     # a copy of an earlier build under build/experimental/ (same-call A/B runs of tools/)
+    LIB_PATH = os.path.join(_EXP_DIR, os.path.basename(os.environ["CVA_LIB"]))
 
 CV_OK, CV_ERR_INVALID, CV_ERR_HIP, CV_ERR_STATE, CV_ERR_SHAPE, CV_ERR_UNSUPPORTED, CV_ERR_MISSING = range(7)
 DTYPE_F16, DTYPE_F32, DTYPE_F8 = 0, 1, 2

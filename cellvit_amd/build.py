@@ -16,8 +16,11 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libcellvit_amd.so")
 # The experiment flavour (-DCVA_ABLATION: CVA_* switches honoured, work-skipping instantiations present) has its own object
 # directory and its own library name: the product library can never be linked from, or mistaken for, ablation objects.
-OBJ_ABL = os.path.join(HERE, "csrc", "_obj_abl")
-LIB_ABL = os.path.join(HERE, "libcellvit_amd_abl.so")
+# Experiment libraries (the ablation flavour, "previous commit" copies for same-call A/B runs) live OUTSIDE the package, under build/experimental/
+# (git-ignored, travels to the GPU box): the package directory holds the product library and nothing else.
+EXP_DIR = os.path.join(os.path.dirname(HERE), "build", "experimental")
+OBJ_ABL = os.path.join(EXP_DIR, "_obj_abl")
+LIB_ABL = os.path.join(EXP_DIR, "libcellvit_amd_abl.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
@@ -36,8 +39,13 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the cellvit_amd HIP extension cannot be built")
 
 
-def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+def sources(ablation: bool = False):
+    """csrc/*.hip = the product; csrc/experiments/*.hip (kernels that lost their A/B and are kept for the record) join the experiment flavour only."""
+    out = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    if ablation:
+        exp = os.path.join(CSRC, "experiments")
+        out += sorted(os.path.join(exp, f) for f in os.listdir(exp) if f.endswith(".hip"))
+    return out
 
 
 def _stale(out: str, deps) -> bool:
@@ -64,9 +72,10 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
         with open(stamp, "w") as f:
             f.write(stamp_text)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    srcs = sources(ablation)
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cellvit_amd.h"))
     jobs = []
-    for src in sources():
+    for src in srcs:
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         if force or _stale(obj, [src] + headers):
             jobs.append((src, obj))
@@ -84,7 +93,7 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
             for s in ex.map(cc, jobs):
                 if verbose:
                     print("[cellvit_amd.build] compiled", os.path.basename(s), file=sys.stderr)
-    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in sources()]
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -35,9 +35,9 @@
 // direct epilogues of gemm8_epi.h apply unchanged to each 128 x 64 half of the wave block; the v columns of the fused qkv
 // projection run with the operands exchanged.  Persistent: one workgroup per CU walks the tile list grid-stride as ONE stream
 // of K tiles (see the kernel): the last K iteration of a tile stages the next tile's first two K tiles.
-#include "gemm.h"
-#include "gemm_epilogue.h"
-#include "gemm8_epi.h"
+#include "../gemm.h"
+#include "../gemm_epilogue.h"
+#include "../gemm8_epi.h"
 
 namespace cva {
 
@@ -356,8 +356,7 @@ int launch4(const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 #ifndef CVA_ABLATION
-bool gemm4_takes(const GemmParams&) { return false; }
-int launch_gemm4(const GemmParams&, int, hipStream_t) { return -1; }
+#error "experiments/gemm4.hip belongs to the experiment flavour of the library only (python -m cellvit_amd.build --ablation)"
 #else
 // Shapes: those of gemm8_supported (the caller checks it); out modes OUT_LINEAR, OUT_QKV and OUT_CONVT with 32-byte runs.
 bool gemm4_takes(const GemmParams& p) {

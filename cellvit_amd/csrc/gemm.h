@@ -95,10 +95,12 @@ template <typename T> int launch_gemm(const GemmParams& p, int a_mode, hipStream
 // gemm8.hip: 256x256x64 8-phase fp16 kernel (A_LINEAR only); launch_gemm routes to it when the shape qualifies.
 bool gemm8_supported(const GemmParams& p, int a_mode, size_t elem_size);
 int launch_gemm8(const GemmParams& p, hipStream_t stream);
-// gemm4.hip: the same tile with ONE wave per SIMD (4 waves x 128 x 128 accumulators); shapes as gemm8_supported, out modes
-// per gemm4_takes.  sched: slot placement variant (ablation builds; production = 1).
+#ifdef CVA_ABLATION
+// experiments/gemm4.hip (experiment flavour of the library only): the same tile with ONE wave per SIMD (4 waves x 128 x 128 accumulators);
+// shapes as gemm8_supported, out modes per gemm4_takes.  sched: slot placement variant.
 bool gemm4_takes(const GemmParams& p);
 int launch_gemm4(const GemmParams& p, int sched, hipStream_t stream);
+#endif
 // fp8 engine: the same kernel on MX-fp8 operands; out_mode OUT_LINEAR (fp32 / fp16 out, optional residual), OUT_QKV or
 // OUT_MX8.  Returns hipErrorInvalidValue when the shape does not qualify (there is no fallback kernel for fp8 operands).
 bool gemm8_f8_supported(const GemmParams& p);

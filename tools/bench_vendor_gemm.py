@@ -1,5 +1,5 @@
 """fc1 / fc2 of the SAM-H step on this repository's kernel and on the vendor library torch dispatches to (hipBLASLt), a few launches each —
-the workload of the PMC comparison (tools/experiments/gpu_r04_j.sh): context for the roofline fractions, never part of the product path.
+the workload of the PMC comparison (profiles/scripts/gpu_r04_j.sh): context for the roofline fractions, never part of the product path.
     python tools/bench_vendor_gemm.py [M] [iters]"""
 import ctypes as C
 import os
