@@ -263,6 +263,10 @@ def _write_cells_pt_holes(path, n_kept, D, tok_chunks, pos_chunks, cont_chunks, 
     from torch.serialization import skip_data
     from ..datamodel import save_cell_graph
     lib = _lib.load()
+    if max(n_kept * D * 4, m * 8) >= (1 << 32) - (1 << 20):
+        # a record of 4 GiB or more makes the archive writer switch to zip64 headers / data descriptors, a layout the hole offsets and CRC patch
+        # positions below have never been checked against: such slides (≈ 1.4e6 SAM-H cells) take the plain torch.save route
+        raise RuntimeError("a cells.pt record of 4 GiB or more: zip64 layout, not filled in place")
     with skip_data():
         route = save_cell_graph(path, torch.empty((n_kept, D), dtype=torch.float32), torch.empty((n_kept, 2), dtype=torch.float32),
                                 torch.empty((m, 2), dtype=torch.float32), lens.tolist(), metadata)

@@ -685,3 +685,33 @@ def test_world2_streamed_tail_files_are_byte_identical_to_world1(tmp_path, grid,
     assert a["writer_gather_bytes_received"] == b["writer_gather_bytes_sent"]
     for name in ("cells.json", "cell_detection.json", "cells.pt"):
         assert (d1 / name).read_bytes() == (d2 / name).read_bytes(), name
+
+
+def test_cells_pt_falls_back_to_torch_save_when_the_in_place_fill_cannot_be_used(tmp_path, monkeypatch):
+    """`write_cells_pt_streamed` promises a cells.pt whatever happens to its skip_data / hole-filling route (another torch, an archive layout it does not
+    know, a short row write): the kept rows of the chunk lists are concatenated and written through the plain route, and the file loads to the same container."""
+    from cellvit_amd.datamodel import install_reference_aliases
+    from cellvit_amd.inference import tail as T
+    rng = np.random.default_rng(5)
+    D = 7
+    toks = [torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32)) for n in (5, 0, 9)]
+    keeps = [rng.integers(0, 2, n).astype(np.uint8) for n in (5, 0, 9)]
+    keeps[0][0] = 1
+    pos = [rng.standard_normal((n, 2)).astype(np.float32) for n in (5, 0, 9)]
+    lens_all = [rng.integers(3, 7, n).astype(np.int64) for n in (5, 0, 9)]
+    cont = [rng.standard_normal((int(l.sum()), 2)).astype(np.float32) for l in lens_all]
+    ckeep = [np.repeat(k, l) for k, l in zip(keeps, lens_all)]
+    lens = np.concatenate([l[k.astype(bool)] for l, k in zip(lens_all, keeps)])
+    n_kept = int(sum(int(k.sum()) for k in keeps))
+    args = (n_kept, D, list(zip(toks, keeps)), list(zip(pos, keeps)), list(zip(cont, ckeep)), lens, {"wsi_metadata": {"a": 1}, "nuclei_types": {"Background": 0}})
+    T.write_cells_pt_streamed(tmp_path / "a.pt", *args)
+
+    def broken(*a, **k):
+        raise RuntimeError("no skip_data in this torch")
+    monkeypatch.setattr(T, "_write_cells_pt_holes", broken)
+    route = T.write_cells_pt_streamed(tmp_path / "b.pt", *args)
+    assert route in ("fast", "torch.save")
+    install_reference_aliases()
+    a, b = torch.load(tmp_path / "a.pt", weights_only=False), torch.load(tmp_path / "b.pt", weights_only=False)
+    assert a.x.shape == (n_kept, D) and torch.equal(a.x, b.x) and torch.equal(a.positions, b.positions) and a.metadata == b.metadata
+    assert len(a.contours) == len(b.contours) == n_kept and all(torch.equal(u, v) for u, v in zip(a.contours, b.contours))
