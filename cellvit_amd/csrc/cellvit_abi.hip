@@ -108,7 +108,8 @@ struct BlockW {
 };
 struct BranchW {
     ConvTW up4; ConvW d3[3]; ConvTW up3; ConvW d2[2]; ConvTW up2; ConvW d1[2]; ConvTW up1; ConvW d0[2]; HeadW head;
-    DeconvCompW k3, k2;       // up4 -> d3[0] and up3 -> d2[0] composed (fp16 engines, Cout % 256 == 0)
+    DeconvCompW k3, k2;       // up4 -> d3[0] and up3 -> d2[0] composed (fp16 engines, Cout % 256 == 0: gemm8.hip)
+    DeconvCompW k1, k0;       // up2 -> d1[0] and up1 -> d0[0] composed (fp16 engines, Cout 128 / 64: deconv.hip)
 };
 
 struct Geometry {
@@ -409,7 +410,9 @@ int pack_convT(cv_handle* h, const std::string& key, int Cin, int Cout, ConvTW* 
 // [skip (Cs, may be 0) || up-sampled (Cup)].
 int pack_deconv_comp(cv_handle* h, const std::string& convT_key, const std::string& conv_key, const std::string& bn_key, int Cin, int Cup,
                      int Cs, int Cout, DeconvCompW* out) {
-    if (is_f32(h->cfg.compute_dtype) || Cout % 256 || Cin % 64 || Cs % 64 || ((4 * Cin + 9 * Cs) / 64) % 2) return CV_OK;   // not a shape the composed kernel takes
+    // shapes a composed kernel takes: Cout % 256 == 0 with an even number of 64-wide K tiles -> launch_gemm8_deconv; Cout <= 128 -> launch_deconv_halo4
+    if (is_f32(h->cfg.compute_dtype) || Cout % 64 || Cin % 64 || Cs % 64) return CV_OK;
+    if (!((Cout % 256 == 0 && ((4 * Cin + 9 * Cs) / 64) % 2 == 0) || Cout <= 128)) return CV_OK;
     static const int use = cva_env_int("CVA_DECONV_COMP", 3);                        // ablation builds (A/B): bit 0 = Deconv2DBlocks, bit 1 = branch stages
     if (!(use & (Cs ? 2 : 1))) return CV_OK;
     const std::string& p = convT_key;
@@ -542,6 +545,8 @@ int pack_branch(cv_handle* h, const std::string& p, int n_out, BranchW* b) {
     CVA_TRY(pack_conv_block(h, p + ".decoder0_header.1", 64, 64, &b->d0[1]));
     CVA_TRY(pack_deconv_comp(h, p + ".bottleneck_upsampler", p + ".decoder3_upsampler.0.block.0", p + ".decoder3_upsampler.0.block.1", D, bott, bott, bott, &b->k3));
     CVA_TRY(pack_deconv_comp(h, p + ".decoder3_upsampler.3", p + ".decoder2_upsampler.0.block.0", p + ".decoder2_upsampler.0.block.1", bott, 256, 256, 256, &b->k2));
+    CVA_TRY(pack_deconv_comp(h, p + ".decoder2_upsampler.2", p + ".decoder1_upsampler.0.block.0", p + ".decoder1_upsampler.0.block.1", 256, 128, 128, 128, &b->k1));
+    CVA_TRY(pack_deconv_comp(h, p + ".decoder1_upsampler.2", p + ".decoder0_header.0.block.0", p + ".decoder0_header.0.block.1", 128, 64, 64, 64, &b->k0));
     const HostTensor* w = find(h, p + ".decoder0_header.2.weight", {n_out, 64, 1, 1}); CVA_NEED(w);
     const HostTensor* bb = find(h, p + ".decoder0_header.2.bias", {n_out}); CVA_NEED(bb);
     b->head.n_out = n_out;
@@ -666,6 +671,16 @@ int run_deconv_block(const void* src, const void* skip, const ConvTW& t, const C
         }
         if (rc == 0) return CV_OK;
         if (rc != -1) { cva_set_error("composed deconv block launch failed (%d)", rc); return CV_ERR_HIP; }
+        static const int halo_on = cva_env_int("CVA_DECONV_HALO4", 1);       // ablation builds (A/B): 0 = two-launch form for the Cout <= 128 stages
+        if (halo_on && k.Cout <= 128 && out != src) {
+            p.zero = gemm_zero_page();
+            {
+                ProfScope ps(KC_CONV3, 2.0 * p.M * (double)p.N * p.K, st);
+                rc = launch_deconv_halo4(p, B, st);
+            }
+            if (rc == 0) return CV_OK;
+            if (rc != -1) { cva_set_error("composed deconv halo launch failed (%d)", rc); return CV_ERR_HIP; }
+        }
     }
     CVA_TRY(run_convT<T>(src, t, tmp, B, Hs, Ws, st));
     if (skip) return run_conv3<T>(skip, c.Ctot - t.Cout, tmp, t.Cout, c, out, 0, B, 2 * Hs, 2 * Ws, st);
@@ -864,11 +879,11 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
         CVA_TRY(run_conv3<T>(S2, bott, nullptr, 0, b.d3[2], S1, 0, B, 2 * gh, 2 * gw, st));
         CVA_TRY(run_deconv_block<T>(S1, h->skip[2], b.up3, b.d2[0], b.k2, S0, S2, B, 2 * gh, 2 * gw, st));
         CVA_TRY(run_conv3<T>(S2, 256, nullptr, 0, b.d2[1], S1, 0, B, 4 * gh, 4 * gw, st));
-        CVA_TRY(run_convT<T>(S1, b.up2, S0, B, 4 * gh, 4 * gw, st));
-        CVA_TRY(run_conv3<T>(h->skip[1], 128, S0, 128, b.d1[0], S1, 0, B, 8 * gh, 8 * gw, st));
-        CVA_TRY(run_conv3<T>(S1, 128, nullptr, 0, b.d1[1], S2, 0, B, 8 * gh, 8 * gw, st));
-        CVA_TRY(run_convT<T>(S2, b.up1, S0, B, 8 * gh, 8 * gw, st));
-        CVA_TRY(run_conv3<T>(h->skip[0], 64, S0, 64, b.d0[0], S1, 0, B, H, W, st));
+        // the two full-resolution stages: ConvTranspose2d o conv3x3 over [skip, up-sampled] as one launch (deconv.hip) where the engine has the
+        // composed filter, else ConvTranspose2d into S0 and the convolution from there (run_deconv_block; output never aliases the input)
+        CVA_TRY(run_deconv_block<T>(S1, h->skip[1], b.up2, b.d1[0], b.k1, S0, S2, B, 4 * gh, 4 * gw, st));
+        CVA_TRY(run_conv3<T>(S2, 128, nullptr, 0, b.d1[1], S1, 0, B, 8 * gh, 8 * gw, st));
+        CVA_TRY(run_deconv_block<T>(S1, h->skip[0], b.up1, b.d0[0], b.k0, S0, S2, B, 8 * gh, 8 * gw, st));
         float* logits = br == 0 ? out->nuclei_binary_map : br == 1 ? out->hv_map : out->nuclei_type_map;
         uint8_t* am = br == 0 ? out->binary_argmax : br == 2 ? out->type_argmax : nullptr;
         const long npix = (long)H * W;
@@ -876,18 +891,18 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
         if (logits && !(br == 0 && c.regression_loss)) {
             hf.W = b.head.W; hf.b = b.head.b; hf.logits = logits; hf.argmax = am; hf.nout = b.head.n_out; hf.narg = b.head.n_out;
         }
-        CVA_TRY(run_conv3<T>(S1, 64, nullptr, 0, b.d0[1], S2, 0, B, H, W, st, hf.W ? &hf : nullptr, &fused));
+        CVA_TRY(run_conv3<T>(S2, 64, nullptr, 0, b.d0[1], S1, 0, B, H, W, st, hf.W ? &hf : nullptr, &fused));
         if (fused) continue;
         if (br == 0 && c.regression_loss) {
             // binary branch carries 2 extra regression channels (cellvit.py:191-196): write the 4-channel
             // result into the scratch logits and split on the fly is not needed — emit two heads.
             HeadW h0 = b.head, h1 = b.head;
             h0.n_out = 2; h1.n_out = 2; h1.W = b.head.W + 2 * 64; h1.b = b.head.b + 2;
-            if (logits) CVA_LAUNCH(launch_head1x1<T>(S2, h0.W, h0.b, logits, am, 2, npix, B, 2, st));
+            if (logits) CVA_LAUNCH(launch_head1x1<T>(S1, h0.W, h0.b, logits, am, 2, npix, B, 2, st));
             if (out->regression_map)
-                CVA_LAUNCH(launch_head1x1<T>(S2, h1.W, h1.b, out->regression_map, nullptr, 0, npix, B, 2, st));
+                CVA_LAUNCH(launch_head1x1<T>(S1, h1.W, h1.b, out->regression_map, nullptr, 0, npix, B, 2, st));
         } else if (logits) {
-            CVA_LAUNCH(launch_head1x1<T>(S2, b.head.W, b.head.b, logits, am, b.head.n_out, npix, B, b.head.n_out, st));
+            CVA_LAUNCH(launch_head1x1<T>(S1, b.head.W, b.head.b, logits, am, b.head.n_out, npix, B, b.head.n_out, st));
         }
     }
     h->last_B = B;
@@ -1426,14 +1441,15 @@ extern "C" int cv_op_deconv_block(const float* wt, const float* bt, const float*
     int rc = pack_deconv_comp(h.get(), "up", "conv", "bn", Cin, Cup, Cs, Cout, &k);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (rc == CV_OK) {
-        if (!k.W) { cva_set_error("cv_op_deconv_block: Cout %% 256 == 0, Cin %% 64 == 0, Cs %% 64 == 0 and an even number of 64-wide K steps required"); rc = CV_ERR_UNSUPPORTED; }
+        if (!k.W) { cva_set_error("cv_op_deconv_block: Cin %% 64 == 0, Cs %% 64 == 0 and either Cout %% 256 == 0 with an even number of 64-wide K steps or Cout in {64, 128}"); rc = CV_ERR_UNSUPPORTED; }
         else {
             GemmParams p{};
             p.M = B * H * W; p.N = 4 * Cout; p.K = 4 * Cin + 9 * Cs; p.A = src; p.A2 = skip; p.C2 = Cs; p.W = k.W; p.ldw = p.K;
             p.H = H; p.Wd = W; p.C1 = Cin;
             p.bias = k.bias4; p.comp_bias = k.btab; p.act = ACT_RELU; p.out_mode = OUT_CONVT; p.out = out;
-            const int r = launch_gemm8_deconv(p, st);
-            if (r == -1) { cva_set_error("cv_op_deconv_block: geometry outside the composed kernel (power-of-two sides, H*W >= 256)"); rc = CV_ERR_UNSUPPORTED; }
+            int r = launch_gemm8_deconv(p, st);
+            if (r == -1 && Cout <= 128) { p.zero = gemm_zero_page(); r = launch_deconv_halo4(p, B, st); }      // the halo kernel of the Cout <= 128 stages (deconv.hip)
+            if (r == -1) { cva_set_error("cv_op_deconv_block: geometry outside the composed kernels (Cout %% 256 == 0: power-of-two sides, H*W >= 256; else Cout <= 128)"); rc = CV_ERR_UNSUPPORTED; }
             else if (r) { cva_set_error("composed deconv block launch failed (%d)", r); rc = CV_ERR_HIP; }
             else if (hipStreamSynchronize(st) != hipSuccess) rc = CV_ERR_HIP;      // the composed weights are freed below
         }

@@ -101,6 +101,11 @@ int launch_gemm8(const GemmParams& p, hipStream_t stream);
 bool gemm4_takes(const GemmParams& p);
 int launch_gemm4(const GemmParams& p, int sched, hipStream_t stream);
 #endif
+// deconv.hip: ConvTranspose2d(k2, s2) o Conv2d 3x3 as a halo-tiled direct convolution (4 waves = the four output parities), for the
+// composed stages with Cout < 256 that launch_gemm8_deconv cannot take.  Same GemmParams contract as launch_gemm8_deconv (+ p.zero);
+// returns -1 when the layer does not fit.
+bool deconv_halo4_supported(const GemmParams& p);
+int launch_deconv_halo4(const GemmParams& p, int batch, hipStream_t stream);
 // fp8 engine: the same kernel on MX-fp8 operands; out_mode OUT_LINEAR (fp32 / fp16 out, optional residual), OUT_QKV or
 // OUT_MX8.  Returns hipErrorInvalidValue when the shape does not qualify (there is no fallback kernel for fp8 operands).
 bool gemm8_f8_supported(const GemmParams& p);

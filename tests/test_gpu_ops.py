@@ -168,7 +168,11 @@ def test_convT2x2(dtype, B, H, W_, Cin, Cout):
 
 
 @pytest.mark.parametrize("B,H,W_,Cin,Cs,Cout", [(2, 16, 16, 128, 0, 256), (1, 32, 16, 64, 0, 256), (1, 4, 64, 192, 0, 512), (3, 16, 16, 320, 0, 256),
-                                                   (2, 16, 16, 128, 256, 256), (1, 8, 32, 64, 128, 256), (1, 2, 256, 192, 128, 512), (3, 16, 16, 128, 384, 256)])
+                                                   (2, 16, 16, 128, 256, 256), (1, 8, 32, 64, 128, 256), (1, 2, 256, 192, 128, 512), (3, 16, 16, 128, 384, 256),
+                                                   # the full-resolution stages (Cout 128 / 64: the halo kernel of deconv.hip — four output parities per workgroup,
+                                                   # parity-split skip halo): the model's two shapes, no skip, several images, partial tiles in both directions
+                                                   (2, 16, 16, 256, 128, 128), (1, 8, 16, 128, 64, 64), (2, 24, 48, 128, 64, 64), (1, 16, 16, 256, 0, 128),
+                                                   (3, 5, 7, 64, 64, 64), (1, 9, 33, 64, 0, 64), (1, 32, 32, 192, 128, 128)])
 def test_deconv_block_composed(B, H, W_, Cin, Cs, Cout):
     """ConvTranspose2d k2 s2 -> Conv2d 3x3 -> BatchNorm2d -> ReLU as one composed launch against the torch modules in fp32 on the same
     (fp16-rounded) inputs.  Cs == 0: Deconv2DBlock (models/segmentation/cell_segmentation/utils.py:46-86); Cs > 0: the convolution runs on
