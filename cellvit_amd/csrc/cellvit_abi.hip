@@ -664,22 +664,22 @@ int run_deconv_block(const void* src, const void* skip, const ConvTW& t, const C
         p.M = B * Hs * Ws; p.N = 4 * k.Cout; p.K = 4 * k.Cin + 9 * k.Cs; p.A = src; p.W = k.W; p.ldw = p.K;
         p.H = Hs; p.Wd = Ws; p.C1 = k.Cin; p.A2 = k.Cs ? skip : nullptr; p.C2 = k.Cs;
         p.bias = k.bias4; p.comp_bias = k.btab; p.act = ACT_RELU; p.out_mode = OUT_CONVT; p.out = out;
-        int rc;
-        {
-            ProfScope ps(KC_CONV3, 2.0 * p.M * (double)p.N * p.K, st);      // executed FLOPs (the two-launch form: 2*M*4*(Cup*Cin + Cout*9*(Cs + Cup)))
-            rc = launch_gemm8_deconv(p, st);
-        }
-        if (rc == 0) return CV_OK;
-        if (rc != -1) { cva_set_error("composed deconv block launch failed (%d)", rc); return CV_ERR_HIP; }
+        // (executed FLOPs; the two-launch form is 2*M*4*(Cup*Cin + Cout*9*(Cs + Cup)).  The kernel is chosen BEFORE the profiling scope opens: a
+        //  scope around a launcher that declines would count the layer's FLOPs twice.)
         static const int halo_on = cva_env_int("CVA_DECONV_HALO4", 1);       // ablation builds (A/B): 0 = two-launch form for the Cout <= 128 stages
-        if (halo_on && k.Cout <= 128 && out != src) {
-            p.zero = gemm_zero_page();
-            {
-                ProfScope ps(KC_CONV3, 2.0 * p.M * (double)p.N * p.K, st);
-                rc = launch_deconv_halo4(p, B, st);
-            }
+        if (gemm8_deconv_supported(p)) {
+            int rc;
+            { ProfScope ps(KC_CONV3, 2.0 * p.M * (double)p.N * p.K, st); rc = launch_gemm8_deconv(p, st); }
             if (rc == 0) return CV_OK;
-            if (rc != -1) { cva_set_error("composed deconv halo launch failed (%d)", rc); return CV_ERR_HIP; }
+            if (rc != -1) { cva_set_error("composed deconv block launch failed (%d)", rc); return CV_ERR_HIP; }
+        } else if (halo_on && k.Cout <= 128 && out != src) {
+            p.zero = gemm_zero_page();
+            if (deconv_halo4_supported(p)) {
+                int rc;
+                { ProfScope ps(KC_CONV3, 2.0 * p.M * (double)p.N * p.K, st); rc = launch_deconv_halo4(p, B, st); }
+                if (rc == 0) return CV_OK;
+                if (rc != -1) { cva_set_error("composed deconv halo launch failed (%d)", rc); return CV_ERR_HIP; }
+            }
         }
     }
     CVA_TRY(run_convT<T>(src, t, tmp, B, Hs, Ws, st));
