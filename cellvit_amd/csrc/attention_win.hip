@@ -589,6 +589,8 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
     const float c1 = p.scale * W_LOG2E;
     int it = blockIdx.x;
     int buf = 0;
+    bool need_q = false;
+    if (((p.dbg & 128) && wave >= 4) || ((p.dbg & 512) && wave < 4)) __builtin_amdgcn_s_setprio(1);      // (experiment: static priority for one half)
     if (it < nitems) { if (!(DBG & 16)) dma_k(it, 0); load_v(it); load_q(it); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // zero fill / E / tables / K image 0 complete
@@ -613,7 +615,16 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         int nk = p.nk, li = li_, g = g_;
         asm volatile("" : "+s"(nk));
         asm volatile("" : "+v"(li), "+v"(g));
-        if (wave_active) {
+        // Window mode: the grid rows of this window that lie past the image (64-wide grid, 14-wide windows: rows 8 .. 13 of the bottom window row)
+        // are padding — window_unpartition drops their outputs (image_encoder.py:297-318).  Query blocks are window rows, so a wave whose two rows
+        // are padding has nothing to compute for this item: it keeps its share of the DMA and the barriers and leaves the SIMD to its partner.
+        if (need_q) { load_q(it); need_q = false; }
+        bool item_active = wave_active;
+        if (p.win > 0 && !(p.dbg & 64)) {
+            const int w = (it / p.heads) % (p.nwx * p.nwy);
+            item_active = wave_active && 2 * wave < p.gh - (w / p.nwx) * p.win;
+        }
+        if (item_active) {
             // ---- rel-pos operands of this wave's two query blocks: bf[qb] = the B fragment of the bias step S^T += E . bf, lane (g, li) =
             // slots 8g .. 8g+7 of query li.  Slot 8g + r carries the kh term for kh = KH-1 - (4g + r), slot 8g + 4 + r the kw term for
             // kw = KW-1 - (4g + r) (E, prepared per layer, has its ones accordingly: attnw_prep_kernel, layout 1).
@@ -706,9 +717,12 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                     __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs between their wait and the ring refill
                 });
             }
+            const bool late_pub = (p.dbg & 256) != 0;   // (experiment: V published behind the softmax instead of in front of it)
             if constexpr (VRM == 2) {                   // this wave's share of V(it) (and of K(next)) has landed; then everybody's
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                if (!late_pub) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
             }
             if (nxt < nitems) load_q(nxt);              // Q of the next item: in flight during the softmax and PV
 
@@ -770,6 +784,12 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                 sum += __shfl_xor(sum, 16);
                 sum += __shfl_xor(sum, 32);
                 inv_l[qb] = 1.0f / sum;
+            }
+            if constexpr (VRM == 2) {
+                if (late_pub) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
             }
             if constexpr ((DBG & 4) != 0) {
 #pragma unroll
@@ -861,6 +881,7 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (VRM == 2) __builtin_amdgcn_s_barrier();   // the barrier behind the active waves' S^T phase
+            need_q = wave_active;                       // (a wave that sat this item out has not asked for the next item's Q)
         }
         __syncthreads();                                // every wave is done with this item's K / V^T; the next K image has landed
     }
