@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--pp-cu-mask", default="",
                     help="EXPERIMENT (recorded in config.experiment_env): run the post-processing stream on a CU-masked HIP stream "
                          "(hipExtStreamCreateWithCUMask); 'N' = N CUs spread evenly over the 256, 'lowN' = the N lowest-numbered CUs")
+    ap.add_argument("--pp-stage", type=int, default=0, choices=[0, 1, 2],
+                    help="when the second stream's post-processing is released: 0 = behind the step's forward (it then runs beside the NEXT step's "
+                         "encoder), 1 / 2 = when the step's forward reaches its decoder / its first full-resolution stage (cv_stream_wait_stage): the "
+                         "chain then runs beside the decoder's short workgroups — in the pipelined tile loop this is the PREVIOUS batch's post-processing")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run post-processing on the forward stream instead of a second HIP stream")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -488,6 +492,8 @@ def main():
         pp_stream = torch.cuda.ExternalStream(sp.value, device=dev)
         dbg = dbg + [f"pp_cu_mask={spec}"]
 
+    armed = set()
+
     def make_step(nb):
         xb = x[:nb]
         pb, pt, ph = (pp_bin[:nb], pp_type[:nb], pp_hv[:nb]) if do_pp else (None, None, None)
@@ -498,7 +504,20 @@ def main():
             out = model.forward_u8(xb, MEAN, STD, retrieve_tokens=True)
             res = None
             if do_pp:
-                if overlap:
+                eng_ = model._last_engine
+                if overlap and args.pp_stage and id(eng_) not in armed:       # first step on this engine: arm, release behind the forward this once
+                    _lib.check(eng_.lib.cv_stream_wait_stage(eng_.h, 0, None))
+                    armed.add(id(eng_))
+                    ev = torch.cuda.Event()
+                    ev.record(main_stream)
+                    with torch.cuda.stream(pp_stream):
+                        pp_stream.wait_event(ev)
+                        res = postprocess_device(pb, pt, ph, 6, 10, 21, want_contours=True)
+                elif overlap and args.pp_stage:
+                    with torch.cuda.stream(pp_stream):
+                        _lib.check(eng_.lib.cv_stream_wait_stage(eng_.h, args.pp_stage, C.c_void_p(pp_stream.cuda_stream)))
+                        res = postprocess_device(pb, pt, ph, 6, 10, 21, want_contours=True)
+                elif overlap:
                     ev = torch.cuda.Event()
                     ev.record(main_stream)
                     with torch.cuda.stream(pp_stream):
@@ -624,7 +643,7 @@ def main():
                        "experiment_env": dbg + (["ABLATION_BUILD"] if _lib.load().cv_build_is_ablation() else []),
                        "library": os.path.relpath(_lib.LIB_PATH, ROOT), "library_build_flags": (_lib.load().cv_build_flags() or b"").decode(),
                        "engine_flags": model.engine_flags(),      # bit 0: window blocks keep V row-major; bit 1: fp8 engine with proj on MX-fp8
-                       "postproc": bool(do_pp), "postproc_stream_overlap": bool(overlap), "postproc_input": f"synthetic nuclei maps, {args.cells} cells/tile",
+                       "postproc": bool(do_pp), "postproc_stream_overlap": bool(overlap), "postproc_release_stage": int(args.pp_stage) if overlap else None, "postproc_input": f"synthetic nuclei maps, {args.cells} cells/tile",
                        "instances_per_step": n_inst},
             "stage_ms_sequential": {"forward": fwd_ms, "postproc": pp_ms},
             "handoff_check": handoff_ms,

@@ -86,6 +86,7 @@ SYMBOLS = {
 }
 
 SYMBOLS.update({
+    "cv_stream_wait_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "cv_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "cv_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "cv_pp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -590,7 +590,6 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
     int it = blockIdx.x;
     int buf = 0;
     bool need_q = false;
-    if (((p.dbg & 128) && wave >= 4) || ((p.dbg & 512) && wave < 4)) __builtin_amdgcn_s_setprio(1);      // (experiment: static priority for one half)
     if (it < nitems) { if (!(DBG & 16)) dma_k(it, 0); load_v(it); load_q(it); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // zero fill / E / tables / K image 0 complete
@@ -617,10 +616,11 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
         asm volatile("" : "+v"(li), "+v"(g));
         // Window mode: the grid rows of this window that lie past the image (64-wide grid, 14-wide windows: rows 8 .. 13 of the bottom window row)
         // are padding — window_unpartition drops their outputs (image_encoder.py:297-318).  Query blocks are window rows, so a wave whose two rows
-        // are padding has nothing to compute for this item: it keeps its share of the DMA and the barriers and leaves the SIMD to its partner.
+        // are padding has nothing to compute for this item: it keeps its share of the DMA and the barriers and leaves the SIMD to its partner
+        // (-2.8 % of the kernel, profiles/r06_e_attnwp_rowskip_ab.txt; static wave priorities and publishing V behind the softmax: +-1 %, same record).
         if (need_q) { load_q(it); need_q = false; }
         bool item_active = wave_active;
-        if (p.win > 0 && !(p.dbg & 64)) {
+        if (p.win > 0) {
             const int w = (it / p.heads) % (p.nwx * p.nwy);
             item_active = wave_active && 2 * wave < p.gh - (w / p.nwx) * p.win;
         }
@@ -717,12 +717,9 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                     __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs between their wait and the ring refill
                 });
             }
-            const bool late_pub = (p.dbg & 256) != 0;   // (experiment: V published behind the softmax instead of in front of it)
             if constexpr (VRM == 2) {                   // this wave's share of V(it) (and of K(next)) has landed; then everybody's
-                if (!late_pub) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
             if (nxt < nitems) load_q(nxt);              // Q of the next item: in flight during the softmax and PV
 
@@ -784,12 +781,6 @@ __global__ __launch_bounds__(PNT) void attnwp_kernel(const AttnParams p) {
                 sum += __shfl_xor(sum, 16);
                 sum += __shfl_xor(sum, 32);
                 inv_l[qb] = 1.0f / sum;
-            }
-            if constexpr (VRM == 2) {
-                if (late_pub) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
             }
             if constexpr ((DBG & 4) != 0) {
 #pragma unroll

@@ -127,6 +127,10 @@ struct cv_handle {
     bool finalized = false;
     int debug = 0;
     int opt_fp8_proj = 1;     // cv_set_option("fp8_proj"): 0 keeps attn.proj on fp16 on the fp8 engine
+    // Stage events of the most recent forward (cv_stream_wait_stage): [0] the encoder is done (the shared skip decoders start), [1] the first
+    // branch reaches its full-resolution stages.  Created on first use, recorded on the forward's stream by every forward from then on.
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool stage_recorded[2] = {false, false};
     std::map<std::string, HostTensor> raw;
     std::vector<void*> allocs;        // weights
     std::vector<void*> ws_allocs;     // workspace (geometry dependent)
@@ -856,6 +860,7 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
     }
 
     // ---- shared skip decoders, evaluated ONCE (F9; the reference re-runs them per branch) ----
+    if (h->stage_ev[0]) { CVA_CHECK_HIP(hipEventRecord(h->stage_ev[0], st)); h->stage_recorded[0] = true; }
     const int gh = g.gh, gw = g.gw;
     void *S0 = h->S[0], *S1 = h->S[1], *S2 = h->S[2];
     CVA_LAUNCH(launch_nchw3_to_nhwc8<T>(x, u8, h->img8, B, H, W, h->dec0[0].Ctot, st));
@@ -881,6 +886,7 @@ int forward_impl(cv_handle* h, const float* x, const InputU8* u8, int B, const c
         CVA_TRY(run_conv3<T>(S2, 256, nullptr, 0, b.d2[1], S1, 0, B, 4 * gh, 4 * gw, st));
         // the two full-resolution stages: ConvTranspose2d o conv3x3 over [skip, up-sampled] as one launch (deconv.hip) where the engine has the
         // composed filter, else ConvTranspose2d into S0 and the convolution from there (run_deconv_block; output never aliases the input)
+        if (br == 0 && h->stage_ev[1]) { CVA_CHECK_HIP(hipEventRecord(h->stage_ev[1], st)); h->stage_recorded[1] = true; }
         CVA_TRY(run_deconv_block<T>(S1, h->skip[1], b.up2, b.d1[0], b.k1, S0, S2, B, 4 * gh, 4 * gw, st));
         CVA_TRY(run_conv3<T>(S2, 128, nullptr, 0, b.d1[1], S1, 0, B, 8 * gh, 8 * gw, st));
         CVA_TRY(run_deconv_block<T>(S1, h->skip[0], b.up1, b.d0[0], b.k0, S0, S2, B, 8 * gh, 8 * gw, st));
@@ -949,6 +955,7 @@ extern "C" int cv_destroy(cv_handle* h) {
     if (!h) return CV_OK;
     free_pool(h->allocs);
     free_pool(h->ws_allocs);
+    for (hipEvent_t e : h->stage_ev) if (e) (void)hipEventDestroy(e);
     delete h;
     return CV_OK;
 }
@@ -1682,6 +1689,19 @@ extern "C" int cv_pp_debug_read(cv_pp* p, const char* name, void* host_dst, size
     if (bytes < need) { cva_set_error("need %zu bytes", need); return CV_ERR_INVALID; }
     CVA_CHECK_HIP(hipDeviceSynchronize());
     CVA_CHECK_HIP(hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+    return CV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage events: a second stream of the caller waits until the most recent forward has reached a stage
+// ------------------------------------------------------------------------------------------------
+extern "C" int cv_stream_wait_stage(cv_handle* h, int stage, void* stream) {
+    if (!h || stage < 0 || stage > 2) { cva_set_error("cv_stream_wait_stage: stage must be 0 (arm only), 1 or 2"); return CV_ERR_INVALID; }
+    for (hipEvent_t& e : h->stage_ev)
+        if (!e) CVA_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (stage == 0) return CV_OK;                 // armed: the next forward records both events
+    if (!h->stage_recorded[stage - 1]) { cva_set_error("cv_stream_wait_stage: no forward has recorded stage %d yet (arm with stage 0 first)", stage); return CV_ERR_STATE; }
+    CVA_CHECK_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), h->stage_ev[stage - 1], 0));
     return CV_OK;
 }
 

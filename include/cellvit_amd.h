@@ -132,6 +132,15 @@ int cv_geometry_flags(const cv_handle* h);
 int cv_set_option(cv_handle* h, const char* name, int value);
 int cv_debug_read(cv_handle* h, const char* name, float* host_dst, size_t capacity, size_t* n_out);
 
+/* Stage events of the forward, for a caller that runs other device work (the post-processing of the PREVIOUS batch, cell_detection.py:306-421
+ * has the two back to back) on a second stream: the encoder's GEMMs are persistent whole-CU workgroups that a co-running latency-bound chain
+ * only time-slices with, the full-resolution decoder stages are short two-per-CU workgroups it interleaves with.
+ *   stage 0: arm (create the events; every later forward records them on its stream);
+ *   stage 1: `stream` waits until the most recent forward has finished its encoder (shared skip decoders start);
+ *   stage 2: ... until its first branch has reached the full-resolution stages.
+ * CV_ERR_STATE if no forward has recorded the stage yet.  No counterpart in the reference (single stream).                              */
+int cv_stream_wait_stage(cv_handle* h, int stage, void* stream);
+
 /* Live per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
  * class while enabled).  Classes: 0 linear GEMM (fp16), 1 QKV GEMM (fp16), 2 conv3x3, 3 convT2x2, 4 attention,
  * 5 MX-fp8 GEMMs of the fp8 engine (qkv, fc1, fc2).
