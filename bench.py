@@ -64,10 +64,11 @@ def parse():
     ap.add_argument("--pp-cu-mask", default="",
                     help="EXPERIMENT (recorded in config.experiment_env): run the post-processing stream on a CU-masked HIP stream "
                          "(hipExtStreamCreateWithCUMask); 'N' = N CUs spread evenly over the 256, 'lowN' = the N lowest-numbered CUs")
-    ap.add_argument("--pp-stage", type=int, default=0, choices=[0, 1, 2],
-                    help="when the second stream's post-processing is released: 0 = behind the step's forward (it then runs beside the NEXT step's "
-                         "encoder), 1 / 2 = when the step's forward reaches its decoder / its first full-resolution stage (cv_stream_wait_stage): the "
-                         "chain then runs beside the decoder's short workgroups — in the pipelined tile loop this is the PREVIOUS batch's post-processing")
+    ap.add_argument("--pp-stage", type=int, default=2, choices=[0, 1, 2],
+                    help="when the second stream's post-processing chain is released: 2 (default, the schedule of the product's tile loop, "
+                         "cell_detection.run_tiles) = when the step's forward reaches its first full-resolution decoder stage (cv_stream_wait_stage) — in the "
+                         "tile loop this is the PREVIOUS batch's post-processing, here the same work on synthetic maps; 1 = when the forward reaches its "
+                         "decoder; 0 = behind the step's forward (the chain then meets the NEXT step's encoder).  Same-call A/B: profiles/r06_f_pp_stage_ab.txt")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run post-processing on the forward stream instead of a second HIP stream")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

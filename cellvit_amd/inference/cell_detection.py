@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import argparse
 import csv
+import ctypes as C
 import json
 import logging
 import math
@@ -31,6 +32,7 @@ import numpy as np
 import torch
 import yaml
 
+from .. import _lib
 from .. import sharding as S
 from ..model import build_model
 from .._lib import REC_DTYPE
@@ -351,6 +353,11 @@ class CellSegmentationInference:
         self.mean = tuple(float(v) for v in norm.get("mean", (0.5, 0.5, 0.5)))
         self.std = tuple(float(v) for v in norm.get("std", (0.5, 0.5, 0.5)))
         self.pool_cap = 2048       # fixed token-pooling slots per tile; tiles with more records take the exact-size pass
+        # The post-processing of batch k runs on a second stream, released when the forward of batch k + 1 reaches its full-resolution decoder
+        # stages (cv_stream_wait_stage): beside the encoder's persistent whole-CU GEMM workgroups the latency-bound chain only time-slices, beside
+        # the decoder's short two-per-CU workgroups it interleaves (profiles/r06_f_pp_stage_ab.txt).  False: forward and post-processing of a
+        # batch back to back on one stream (the reference's order, cell_detection.py:306-421).  Same results either way.
+        self.overlap_postproc = True
 
     def _normalize(self, tiles_u8: torch.Tensor) -> torch.Tensor:
         """T.ToTensor + T.Normalize (:214-227) as a stand-alone device op: [B,H,W,3] u8 -> [B,3,H,W] f32.  The tile
@@ -396,14 +403,40 @@ class CellSegmentationInference:
                 pinned[i] = have
             return have
 
-        def enqueue(ids, x_u8, mds):
+        pp_stream = torch.cuda.Stream(self.device) if self.overlap_postproc else None
+        armed = [False]
+
+        def forward_only(ids, x_u8, mds):
             pred = self.model.forward_u8(x_u8, self.mean, self.std, retrieve_tokens=True)
-            bin_am, typ_am = self.model._last_argmax              # argmax planes written by the forward kernels
-            inst, recs, n_recs, contours, n_pts = postprocess_device(bin_am, typ_am, pred["hv_map"],
-                                                                     self.model.num_nuclei_classes, obj, ks)
-            pooled, cap = pool_cell_tokens_fixed(pred["tokens"], recs, n_recs, self.model.patch_size, cap=self.pool_cap)
-            ev = torch.cuda.Event()
-            ev.record()
+            if pp_stream is not None and not armed[0]:            # from the next forward on, the engine records its stage events
+                e = getattr(self.model, "_last_engine", None)
+                if e is not None:
+                    _lib.check(e.lib.cv_stream_wait_stage(e.h, 0, None))
+                    armed[0] = True
+            return ids, mds, pred, self.model._last_argmax        # argmax planes written by the forward kernels
+
+        def enqueue(fw, staged):
+            """Post-processing, token pooling and the device -> host copies of one forwarded batch.  staged: the NEXT batch's forward has been
+            enqueued behind it — the chain is released when that forward reaches its full-resolution stages; else behind everything enqueued."""
+            ids, mds, pred, (bin_am, typ_am) = fw
+            compute = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(pp_stream if pp_stream is not None else compute):
+                if pp_stream is not None:
+                    if staged and armed[0]:
+                        e = self.model._last_engine
+                        _lib.check(e.lib.cv_stream_wait_stage(e.h, 2, C.c_void_p(pp_stream.cuda_stream)))
+                    else:                                          # (last batch, or a model without stage events)
+                        pp_stream.wait_stream(compute)
+                    for t_ in (bin_am, typ_am, pred["hv_map"], pred["tokens"]):     # allocated on the compute stream, read on this one
+                        t_.record_stream(pp_stream)
+                inst, recs, n_recs, contours, n_pts = postprocess_device(bin_am, typ_am, pred["hv_map"],
+                                                                         self.model.num_nuclei_classes, obj, ks)
+                pooled, cap = pool_cell_tokens_fixed(pred["tokens"], recs, n_recs, self.model.patch_size, cap=self.pool_cap)
+                ev = torch.cuda.Event()
+                ev.record()
+                if pp_stream is not None:                          # finish() may run the exact-size pooling pass on the compute stream
+                    for t_ in (recs, n_recs):
+                        t_.record_stream(compute)
             host = pinned_like(turn[0], recs, n_recs, contours, n_pts)
             turn[0] ^= 1
             with torch.cuda.stream(copy_stream):
@@ -423,7 +456,8 @@ class CellSegmentationInference:
             if (nr > cap).any():                                   # rare: a tile with more cells than fixed pooling slots
                 exact, off = pool_cell_tokens(tokens, recs, n_recs, self.model.patch_size)
                 pooled = [exact[int(off[b]):int(off[b]) + int(nr[b])] for b in range(len(ids))]   # per-tile rows
-                copy_stream.wait_stream(torch.cuda.current_stream(self.device))     # (this pass ran on the compute stream)
+                copy_stream.wait_stream(torch.cuda.current_stream(self.device))     # (this pass ran on the compute stream; recs / tokens are complete:
+                                                                                    #  this batch's copies, behind its whole chain, were waited for above)
             mx_r, mx_p = int(nr.max()), int(npt.max())
             rec_h = recs_h[:, :mx_r].numpy().view(REC_DTYPE).reshape(len(ids), mx_r)
             pts_h = pts_all[:, :mx_p].numpy()
@@ -468,14 +502,30 @@ class CellSegmentationInference:
         t0 = time.perf_counter()
         pending = None
         with torch.no_grad(), torch.cuda.device(self.device):
+            prev_fw = None
             for ids, x_u8, mds in TilePrefetcher(wsi, tile_ids, batch_size, self.device, num_workers):
-                job = enqueue(ids, x_u8, mds)
+                fw = forward_only(ids, x_u8, mds)
+                if pp_stream is None:
+                    job = enqueue(fw, False)
+                elif prev_fw is not None:
+                    job = enqueue(prev_fw, True)                   # the previous batch's chain, beside this batch's decoder
+                else:
+                    job = None
+                prev_fw = fw if pp_stream is not None else None
+                if job is not None:
+                    if pending is not None:
+                        finish(pending)
+                    pending = job
+            if prev_fw is not None:                                # the last batch: nothing follows it
+                job = enqueue(prev_fw, False)
                 if pending is not None:
                     finish(pending)
                 pending = job
             if pending is not None:
                 finish(pending)
             copy_stream.synchronize()
+            if pp_stream is not None:
+                pp_stream.synchronize()
         stats["t_loop"] = time.perf_counter() - t0
         if tail is not None:      # the tail holds the batches; the caller only counts the cells
             ir = np.concatenate([p.ir for p in parts]) if parts else None

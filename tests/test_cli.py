@@ -457,6 +457,17 @@ def test_cli_end_to_end_tiny_slide(tmp_path):
         assert {"bbox", "centroid", "contour", "type_prob", "type", "patch_coordinates", "cell_status",
                 "offset_global", "edge_position"} <= set(c.keys())
     assert (out / "cell_detection.json").exists() and (out / "cells.geojson").exists()
+    # the tile loop with the real engine, one tile per batch: the post-processing of batch 0 is released by the stage event of batch 1's forward
+    # (cv_stream_wait_stage) on the second stream — same cells and token rows as the back-to-back order on one stream
+    inf = CD.CellSegmentationInference(str(tmp_path / "ckpt.pth"), 0)
+    wsi = CD.PatchedSlide("slide", str(slide))
+    assert inf.overlap_postproc
+    a, pa, _ = inf.run_tiles(wsi, [0, 1], batch_size=1)
+    inf.overlap_postproc = False
+    b, pb, _ = inf.run_tiles(wsi, [0, 1], batch_size=1)
+    assert pa == pb == ["0_0", "0_1"] and len(a) == len(b)
+    assert np.array_equal(a.ir, b.ir) and np.array_equal(a.fr, b.fr) and np.array_equal(a.ct, b.ct)
+    assert (a.tokens is None and b.tokens is None) or torch.equal(a.tokens.cpu(), b.tokens.cpu())
     print(f"\n[cli] real CellViT-256 (random weights) on 2 tiles: {len(cells['cells'])} cells written")
 
 
@@ -558,6 +569,13 @@ def test_cli_route_with_real_cells_against_the_oracle(tmp_path):
     local2, _, _ = inf.run_tiles(wsi, [0, 1, 2, 3], batch_size=3)
     inf.pool_cap = 2048
     assert np.array_equal(local2.ir, local.ir) and torch.equal(local2.tokens.cpu(), local.tokens.cpu())
+    # ---- the second-stream post-processing (default) and the back-to-back order of the reference produce the same cells
+    assert inf.overlap_postproc
+    inf.overlap_postproc = False
+    local3, processed3, _ = inf.run_tiles(wsi, [0, 1, 2, 3], batch_size=3)
+    inf.overlap_postproc = True
+    assert processed3 == processed and np.array_equal(local3.ir, local.ir) and np.array_equal(local3.fr, local.fr)
+    assert np.array_equal(local3.ct, local.ct) and torch.equal(local3.tokens.cpu(), local.tokens.cpu())
     # ---- whole CLI call: files == one global stitch of those cells
     res = inf.process_wsi(wsi, batch_size=3, geojson=True)
     assert res["margin_records"] > 0 and res["margin_kept"] < res["margin_records"]
