@@ -403,7 +403,7 @@ class CellSegmentationInference:
                 pinned[i] = have
             return have
 
-        pp_stream = torch.cuda.Stream(self.device) if self.overlap_postproc else None
+        pp_stream = torch.cuda.Stream(self.device) if getattr(self, "overlap_postproc", True) else None
         armed = [False]
 
         def forward_only(ids, x_u8, mds):

@@ -40,6 +40,10 @@ class WorldMapsModel:
         self.hv = torch.from_numpy(np.stack([c[2] for c in crops])).to(device)
         self._last_argmax = None
 
+    @property
+    def _last_engine(self):           # (the tile loop releases the previous batch's post-processing by the engine's stage event)
+        return self.real._last_engine
+
     def forward_u8(self, x_u8, mean, std, retrieve_tokens=False):
         out = self.real.forward_u8(x_u8, mean, std, retrieve_tokens=retrieve_tokens)
         cls = x_u8[:, 0, 0, 0].long()
@@ -85,7 +89,8 @@ def build_slide(tmp, tiles, model, with_ckpt=True):
     return os.path.join(tmp, "ckpt.pth"), slide
 
 
-def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batches=2, world_seed=3, real_model=None, slides=1, stream_tail=True):
+def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batches=2, world_seed=3, real_model=None, slides=1, stream_tail=True,
+        overlap_postproc=True):
     """One slide through process_wsi on this process's rank; returns the stats dict of rank 0 (None on other ranks).
     `real_model`: an already built cellvit_amd model (bench.py's); otherwise a seeded checkpoint is written and loaded
     through the CLI's own checkpoint path."""
@@ -115,6 +120,7 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
         inf.device = torch.device("cuda", torch.cuda.current_device())
         inf.run_conf = {"dataset_config": {"nuclei_types": NUCLEI_TYPES}}
         inf.mixed_precision, inf.model, inf.mean, inf.std, inf.pool_cap = True, real_model, (0.5,) * 3, (0.5,) * 3, 2048
+    inf.overlap_postproc = overlap_postproc
     inf.model = WorldMapsModel(inf.model, synth_world_maps(world_seed, 1920, 2800), inf.device)
     wsi = CD.PatchedSlide("slide", slide)
     inf.run_tiles(wsi, list(range(min(tiles, warmup_batches * batch))), batch)               # warm-up (engine, workspaces)
@@ -146,6 +152,7 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
             "exchange_s": stats["exchange_s"], "stitch_s": stats["stitch_s"], "to_dicts_s": stats["to_dicts_s"],
             "margin_bytes_all_gathered": stats.get("margin_bytes_all_gathered"), "writer_gather_bytes_received_rank0": stats.get("writer_gather_bytes_received"),
             "write_s": stats["write_s"], "slide_total_s": total, "slide_tiles_per_s": tiles / total,
+            "postproc_schedule": "second stream, released by the next forward's full-resolution stage event" if overlap_postproc else "back to back on one stream",
             "tail_s": total - stats["t_loop"], "tail_route": "streamed" if stream_tail else "batch", "tail_wait_workers_s": stats.get("tail_wait_workers_s"), "tail_breakdown_s": stats.get("tail_breakdown_s"),
             "output_MB": out_bytes / 1e6, "host_cpus": os.cpu_count(), "dataset_mode": dataset}
 
@@ -162,6 +169,7 @@ def main():
     ap.add_argument("--geojson", action="store_true")
     ap.add_argument("--tmp", default=None)
     ap.add_argument("--slides", type=int, default=1, help="> 1: additionally run that many slides back to back with deferred writers")
+    ap.add_argument("--serial-postproc", action="store_true", help="forward and post-processing of a batch back to back on one stream (the reference's order)")
     ap.add_argument("--batch-tail", action="store_true", help="the batch route of the slide tail (finalize_slide + write_outputs) instead of the streaming one")
     args = ap.parse_args()
     if args.ranks > 1 and "WORLD_SIZE" not in os.environ:
@@ -188,7 +196,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")               # all ranks share the box's one GPU: host-side exchange
-    rec = run(args.tiles, args.batch, args.model, args.geojson, args.tmp, slides=args.slides, stream_tail=not args.batch_tail)
+    rec = run(args.tiles, args.batch, args.model, args.geojson, args.tmp, slides=args.slides, stream_tail=not args.batch_tail,
+              overlap_postproc=not args.serial_postproc)
     if rec is not None:
         print(json.dumps(rec))
     if dist.is_initialized():
