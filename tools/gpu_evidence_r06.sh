@@ -38,5 +38,12 @@ python tools/bench_slide.py --tiles 1024 --batch 16 --ranks 2 --backend gloo > $
 python bench.py --gpus 2 --backend gloo --share-gpu --batch 16 --steps 3 --warmup 1 2> $OUT/bench_2ranks_gloo.err | grep '^{' > $OUT/bench_2ranks_gloo.json
 # the reference CLI's default batch (8 tiles per step): classes of that step
 python bench.py --batch 8 --no-extras --no-cpu-baseline --steps 20 --warmup 4 > $OUT/bench_f16_batch8.json 2> $OUT/bench_f16_batch8.err
-tools/probes/_bin/probe_mfma_shape > $OUT/probe_mfma_shape.txt 2>&1
+# the reference CLI's default batch through the real tile loop, and the loop's one-stream form beside it
+python tools/bench_slide.py --tiles 1024 --batch 8 > $OUT/slide_1024_b8.json 2> $OUT/slide_1024_b8.err
+python tools/bench_slide.py --tiles 1024 --batch 8 --serial-postproc > $OUT/slide_1024_b8_serial.json 2> $OUT/slide_1024_b8_serial.err
+python tools/bench_slide.py --tiles 1024 --batch 16 --serial-postproc > $OUT/slide_1024_b16_serial.json 2> $OUT/slide_1024_b16_serial.err
+python tools/bench_slide.py --tiles 1024 --batch 16 --model vit256 > $OUT/slide_1024_b16_vit256.json 2> $OUT/slide_1024_b16_vit256.err
+# rounds 2-5's release point of the post-processing stream, for the record
+python bench.py --pp-stage 0 --no-extras --no-cpu-baseline > $OUT/bench_f16_pp_stage0.json 2> $OUT/bench_f16_pp_stage0.err
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt >> $OUT/rc.txt
 cat $OUT/rc.txt; cat $OUT/slide_1024_b16.json $OUT/slide_1024_b64.json $OUT/slide_1024_b16_2ranks.json; head -8 $OUT/kernel_insts.txt | cut -c1-250
