@@ -216,3 +216,34 @@ def test_capacity_overflow_is_reported():
         assert 0 < len(PP.records_to_dicts(recs3, n_recs3, contours3, n_pts3)[0]) <= int(n_recs[0])
     finally:
         PP.set_capacity()
+
+
+def test_stage_events_order_a_second_stream_behind_the_forward():
+    """cv_stream_wait_stage (the tile loop's release point for the previous batch's post-processing): not before a forward has recorded the
+    stage; once armed, work enqueued on a second stream behind stage 2 / stage 1 sees everything the forward wrote BEFORE that stage (the tokens
+    come out of the encoder, ahead of both stages), and the forward's results do not depend on the events."""
+    import ctypes as C
+    from cellvit_amd import _lib
+    from cellvit_amd.weights import synthetic_tile_u8
+    cfg, sd, _, _ = load_case("vit256_256")
+    m = _model(cfg, sd, "fp16")
+    u8 = torch.from_numpy(np.stack([synthetic_tile_u8(i, size=256, he_like=True) for i in range(2)])).cuda()
+    ref = {k: v.clone() for k, v in m.forward_u8(u8, retrieve_tokens=True).items()}
+    e = m._last_engine
+    s2 = torch.cuda.Stream()
+    with pytest.raises(ValueError):
+        _lib.check(e.lib.cv_stream_wait_stage(e.h, 3, C.c_void_p(s2.cuda_stream)))
+    _lib.check(e.lib.cv_stream_wait_stage(e.h, 0, None))                  # arm
+    with pytest.raises(RuntimeError):                                     # armed, but no forward has recorded the stages yet
+        _lib.check(e.lib.cv_stream_wait_stage(e.h, 2, C.c_void_p(s2.cuda_stream)))
+    for stage in (1, 2):
+        out = m.forward_u8(u8, retrieve_tokens=True)
+        with torch.cuda.stream(s2):
+            _lib.check(e.lib.cv_stream_wait_stage(e.h, stage, C.c_void_p(s2.cuda_stream)))
+            tok = out["tokens"].clone()                                    # on s2, ordered behind the stage event only
+            out["tokens"].record_stream(s2)
+        s2.synchronize()
+        assert torch.equal(tok, ref["tokens"])
+        torch.cuda.synchronize()
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), k
