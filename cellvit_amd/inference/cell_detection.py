@@ -379,6 +379,8 @@ class CellSegmentationInference:
         """The tile loop (cell_detection.py:306-421) for one rank's tiles.  Per batch: raw u8 tiles -> forward (HIP) ->
         post-processing on the argmax planes the forward wrote (HIP) -> cell-token pooling (HIP); then the record / contour
         arrays go to pinned host buffers on a copy stream.  Host work of batch k (array unpacking) overlaps the GPU work of k+1.
+        With `overlap_postproc` (default) the post-processing + pooling of batch k run on a second stream, released when the forward of
+        batch k+1 reaches its full-resolution decoder stages (cv_stream_wait_stage); the last batch's chain follows its own forward.
         `tail` (a `tail.SlideTail`): every finished batch is handed to the streaming slide tail — token rows leave the device per
         batch, geometry and JSON text are prepared by its worker threads while the loop runs; the returned cells then carry no tokens."""
         nuclei_types = self.run_conf["dataset_config"]["nuclei_types"]
@@ -479,8 +481,8 @@ class CellSegmentationInference:
                 else:
                     idx = torch.as_tensor(np.concatenate(rows) if rows else np.zeros(0, np.int64), dtype=torch.long, device=pooled.device)
                     tok = pooled.reshape(-1, pooled.shape[-1]).index_select(0, idx)
-                # cross-stream lifetimes for the caching allocator: `pooled` was allocated on the compute stream and is read here on
-                # the copy stream (the job is dropped right after); `tok` is allocated on the copy stream and read later by
+                # cross-stream lifetimes for the caching allocator: `pooled` was allocated on the post-processing (or compute) stream and is
+                # read here on the copy stream (the job is dropped right after); `tok` is allocated on the copy stream and read later by
                 # torch.cat / select on the compute stream
                 for t_ in (pooled if isinstance(pooled, list) else [pooled]):
                     t_.record_stream(copy_stream)
