@@ -69,8 +69,6 @@ def parse():
                          "cell_detection.run_tiles) = when the step's forward reaches its first full-resolution decoder stage (cv_stream_wait_stage) — in the "
                          "tile loop this is the PREVIOUS batch's post-processing, here the same work on synthetic maps; 1 = when the forward reaches its "
                          "decoder; 0 = behind the step's forward (the chain then meets the NEXT step's encoder).  Same-call A/B: profiles/r06_f_pp_stage_ab.txt")
-    ap.add_argument("--pp-priority", type=int, default=0,
-                    help="EXPERIMENT (recorded in config.experiment_env when not 0): HIP priority of the post-processing stream (-1 = high, 0 = normal)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run post-processing on the forward stream instead of a second HIP stream")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -478,9 +476,7 @@ def main():
 
     overlap = do_pp and not args.no_overlap
     main_stream = torch.cuda.current_stream(dev)
-    pp_stream = torch.cuda.Stream(dev, priority=args.pp_priority) if overlap else main_stream
-    if overlap and args.pp_priority:
-        dbg = dbg + [f"pp_priority={args.pp_priority}"]
+    pp_stream = torch.cuda.Stream(dev) if overlap else main_stream
     if overlap and args.pp_cu_mask:
         import ctypes as _C
         hip = _C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))

@@ -2,7 +2,7 @@
 # round 6, call i: HIP priority of the post-processing stream under the staged schedule (--pp-stage 2): normal against high; same call, alternating
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r06_i; mkdir -p $O
-for v in 0 -1 0 -1; do
+for v in 0 -1 0 -1; do   # (--pp-priority: torch.cuda.Stream(dev, priority=v) for the post-processing stream; removed from bench.py after this call)
   timeout 600 python bench.py --no-cpu-baseline --no-extras --pp-priority $v --steps 10 > $O/b.log 2>$O/b.err
   python - "$v" $O/b.log <<'PY' | tee -a $O/pp_priority_ab.txt
 import json, sys
