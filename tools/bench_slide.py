@@ -142,6 +142,14 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
     out_bytes = sum(os.path.getsize(os.path.join(stats["outdir"], f)) for f in os.listdir(stats["outdir"])) if rank == 0 else 0
     if rank != 0:
         return None
+    import hashlib
+    digests = {}
+    for f in ("cells.json", "cell_detection.json"):          # (outside every timed interval) so that two runs of the same slide can be compared byte for byte
+        h = hashlib.sha256()
+        with open(os.path.join(stats["outdir"], f), "rb") as fh:
+            for blk in iter(lambda: fh.read(1 << 24), b""):
+                h.update(blk)
+        digests[f] = h.hexdigest()[:16]
     return {"tool": "bench_slide", "model": model, "tiles": tiles, "batch": batch, "ranks": world_n,
             "collective_backend": dist.get_backend() if dist.is_initialized() else None,
             "exchange_buffers": ("device" if dist.get_backend() == "nccl" else "host") if dist.is_initialized() else None,
@@ -154,7 +162,7 @@ def run(tiles=1024, batch=16, model="samh", geojson=False, tmp=None, warmup_batc
             "write_s": stats["write_s"], "slide_total_s": total, "slide_tiles_per_s": tiles / total,
             "postproc_schedule": "second stream, released by the next forward's full-resolution stage event" if overlap_postproc else "back to back on one stream",
             "tail_s": total - stats["t_loop"], "tail_route": "streamed" if stream_tail else "batch", "tail_wait_workers_s": stats.get("tail_wait_workers_s"), "tail_breakdown_s": stats.get("tail_breakdown_s"),
-            "output_MB": out_bytes / 1e6, "host_cpus": os.cpu_count(), "dataset_mode": dataset}
+            "output_MB": out_bytes / 1e6, "output_sha256_16": digests, "host_cpus": os.cpu_count(), "dataset_mode": dataset}
 
 
 def main():
